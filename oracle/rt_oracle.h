@@ -1,0 +1,129 @@
+/*
+ * rt_oracle.h — CPU restatement of the reference's kd-tree traversal / leaf-packet
+ * Möller–Trumbore / render-loop hot path (SURVEY.md §8a rows a1–a16).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library.  The shipped path
+ * (simd-raytracer_amd/) never links, imports or calls anything in oracle/.
+ *
+ * PARITY PIN STATUS: the reference itself cannot be built in this image without
+ * stand-in headers (needs libstdc++ >= 13, simdjson and stb fetched from the network),
+ * and it ships no tests or golden vectors.  This restatement is therefore pinned only
+ * by the reference-measured counters recorded in SURVEY.md §6/§8 (tree topology,
+ * intersect-call counts per frame, per-ray node/packet averages) — see
+ * tests/test_oracle_pins.py.  Per-pixel parity against a reference *binary* is
+ * "parity unpinned".
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/include/raytracer/).
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORA_MAT_DIFFUSE = 0, ORA_MAT_REFLECTIVE = 1, ORA_MAT_REFRACTIVE = 2, ORA_MAT_CONSTANT = 3 };
+enum { ORA_ACCEL_KD_SIMD = 0, ORA_ACCEL_KD_SCALAR = 1 };
+
+typedef struct ora_scene ora_scene;
+typedef struct ora_accel ora_accel;
+
+/* Flattened scene (what io/json/loader.hpp:235-265 produces, as arrays). */
+typedef struct {
+    int32_t n_meshes;
+    const int32_t *mesh_material;  /* [n_meshes] */
+    const int32_t *mesh_nverts;    /* [n_meshes] */
+    const int32_t *mesh_ntris;     /* [n_meshes] */
+    const float *vertices;         /* concatenated [sum nverts][3] */
+    const uint32_t *indices;       /* concatenated [sum ntris][3], mesh-local */
+    int32_t n_materials;
+    const int32_t *mat_kind;       /* [n_materials] ORA_MAT_* */
+    const float *mat_albedo;       /* [n_materials][3] */
+    const float *mat_ior;          /* [n_materials] */
+    const int32_t *mat_smooth;     /* [n_materials] */
+    int32_t n_lights;
+    const float *light_pos;        /* [n_lights][3] */
+    const float *light_intensity;  /* [n_lights] */
+    float cam_pos[3];
+    float cam_mat[9];              /* row-major, as in the .crtscene */
+    float background[3];
+    int32_t width, height, bucket_size;
+} ora_scene_desc;
+
+/* Runtime form of config.hpp:6-17 (compile-time constants in the reference). */
+typedef struct {
+    int32_t width, height;         /* 0 = take from scene */
+    int32_t spp;                   /* samples_per_pixel */
+    int32_t max_depth;             /* max_ray_depth */
+    int32_t diffuse_rays;          /* diffuse_reflection_ray_count */
+    uint32_t seed;                 /* fixed_rng_seed */
+    double fov_degrees;
+    float shadow_bias, reflection_bias, refraction_bias;
+    int32_t n_threads;             /* 0 = hardware concurrency */
+} ora_render_params;
+
+/* 32-byte hit record, same layout as rtk_hit in include/rtk.h. */
+typedef struct {
+    float t, u, v;                 /* t < 0 => miss */
+    uint32_t tri;                  /* global triangle index, 0xFFFFFFFF on miss */
+    uint32_t mesh;
+    float normal[3];               /* hit_normal */
+} ora_hit;
+
+/* counters[] slots */
+enum {
+    ORA_C_RAYS = 0,      /* intersect() invocations */
+    ORA_C_HITS,          /* invocations that returned a hit */
+    ORA_C_NODES,         /* tree nodes popped */
+    ORA_C_BOXPASS,       /* nodes whose box test passed (incl. best_t prune) */
+    ORA_C_LEAVES,        /* leaves entered */
+    ORA_C_PACKETS,       /* W-wide packets tested (kd_simd) */
+    ORA_C_TRIS,          /* unpadded triangles tested */
+    ORA_C_PRIMARY,       /* camera rays */
+    ORA_C_COUNT
+};
+
+ora_scene *ora_scene_create(const ora_scene_desc *d);
+void ora_scene_destroy(ora_scene *s);
+
+/* kind: ORA_ACCEL_KD_SIMD (kd_tree_simd.hpp) or ORA_ACCEL_KD_SCALAR (kd_tree.hpp).
+ * W is the packet width for KD_SIMD (native_simd<float>::size() in the reference). */
+ora_accel *ora_accel_build(const ora_scene *s, int kind, float eps, int max_depth, int max_leaf, int W);
+void ora_accel_destroy(ora_accel *a);
+
+/* Tree introspection (reference node order = creation order, kd_tree_simd.hpp:146-185). */
+int64_t ora_accel_num_nodes(const ora_accel *a);
+int64_t ora_accel_num_packets(const ora_accel *a);
+int64_t ora_accel_num_leaf_refs(const ora_accel *a);     /* unpadded */
+int64_t ora_accel_num_triangles(const ora_accel *a);
+/* nodes_box [n][6] (min xyz, max xyz); nodes_link [n][4] = child0, child1, leaf_start (into the
+ * unpadded leaf-ref array, -1 for inner), leaf_count (unpadded). */
+void ora_accel_dump(const ora_accel *a, float *nodes_box, int32_t *nodes_link, int32_t *leaf_refs);
+/* vertex normals of mesh m (mesh.hpp:23-44), [nverts][3] */
+void ora_scene_vertex_normals(const ora_scene *s, int mesh, float *out);
+
+/* Batched closest-hit: rays [n][6] = origin xyz, direction xyz. */
+void ora_intersect(const ora_accel *a, const float *rays, size_t n, int cull, ora_hit *out,
+                   uint64_t *counters /* ORA_C_COUNT, accumulated; may be NULL */);
+
+/* render_frame (render/render.hpp:18-108).  rgb [h][w][3] float. */
+int ora_render_frame(const ora_accel *a, const ora_render_params *p, float *rgb,
+                     uint64_t *counters /* ORA_C_COUNT, overwritten; may be NULL */);
+
+/* write_ppm (io/image/ppm.hpp:7-25): returns bytes written into buf (or needed if buf==NULL). */
+size_t ora_write_ppm(const float *rgb, int width, int height, char *buf, size_t cap);
+
+/* Counter-based RNG shared by the oracle and the HIP path (replaces utils/rand.hpp:5-19). */
+float ora_urand01(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter);
+/* deterministic sin/cos used for GI directions on both sides */
+void ora_sincos(float angle, float *s, float *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
