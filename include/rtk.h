@@ -1,0 +1,195 @@
+/*
+ * rtk.h — C-ABI of the MI355X-native kd-tree traversal / ray-triangle intersection engine.
+ *
+ * This is the drop-in boundary for ONE path of MihailMihov/simd-raytracer: everything a caller
+ * reaches through the reference's `accelerator` concept and `render_frame` for
+ * `kd_tree_simd_accel`.  Plain pointers and sizes only; no C++/torch types; never throws.
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/include/raytracer/).  The reference-side binding a maintainer would add is
+ * in INTEGRATION.md; the header-only C++ adapter modelling the concept is
+ * simd-raytracer_amd/hip_accel.hpp.
+ *
+ * There is NO CPU fallback behind this interface: compute entry points return
+ * RTK_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef RTK_H
+#define RTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTK_ABI_VERSION 1
+
+/* status codes (reference: intersect is noexcept, miss = nullopt, kd_tree_simd.hpp:188,231;
+ * loader throws std::invalid_argument, io/json/loader.hpp:104,127,145,170,190,224) */
+enum {
+    RTK_OK = 0,
+    RTK_ERR_INVALID = 1,      /* bad argument / malformed description */
+    RTK_ERR_NO_DEVICE = 2,    /* no usable HIP device: the product has no CPU path */
+    RTK_ERR_HIP = 3,          /* a HIP runtime call failed */
+    RTK_ERR_IO = 4,           /* file could not be read / written */
+    RTK_ERR_PARSE = 5,        /* .crtscene is not valid JSON or misses a required key */
+    RTK_ERR_UNSUPPORTED = 6   /* feature outside the accelerated path (texture materials) */
+};
+
+/* material kinds: scene/material/material.hpp:12 (texture_material is out of scope) */
+enum { RTK_MAT_DIFFUSE = 0, RTK_MAT_REFLECTIVE = 1, RTK_MAT_REFRACTIVE = 2, RTK_MAT_CONSTANT = 3 };
+
+/* traversal strategy of the device kernels; all three give bit-identical results */
+enum {
+    RTK_TRACE_AUTO = 0,   /* wave-cooperative while the wave's rays agree, per-lane otherwise */
+    RTK_TRACE_LANE = 1,   /* one ray per lane, independent stackless traversal */
+    RTK_TRACE_WAVE = 2    /* one wave walks the tree once for its 64 rays (scalar node/triangle fetch) */
+};
+
+typedef struct rtk_scene rtk_scene;   /* replaces scene<F>, scene/scene.hpp:14-22 */
+typedef struct rtk_accel rtk_accel;   /* replaces kd_tree_simd_accel<F,eps,...>, render/accel/kd_tree_simd.hpp:63-98 */
+
+/* Flattened scene<F>: what parse_scene_file (io/json/loader.hpp:235-265) produces. */
+typedef struct {
+    int32_t n_meshes;
+    const int32_t *mesh_material;   /* [n_meshes]  mesh_object::material_idx */
+    const int32_t *mesh_nverts;     /* [n_meshes] */
+    const int32_t *mesh_ntris;      /* [n_meshes] */
+    const float *vertices;          /* concatenated [sum nverts][3] */
+    const uint32_t *indices;        /* concatenated [sum ntris][3], mesh-local vertex indices */
+    int32_t n_materials;
+    const int32_t *mat_kind;        /* [n_materials] RTK_MAT_* */
+    const float *mat_albedo;        /* [n_materials][3] */
+    const float *mat_ior;           /* [n_materials] */
+    const int32_t *mat_smooth;      /* [n_materials] smooth_shading */
+    int32_t n_lights;
+    const float *light_pos;         /* [n_lights][3] */
+    const float *light_intensity;   /* [n_lights] */
+    float cam_pos[3];               /* camera::position, scene/camera.hpp:10 */
+    float cam_mat[9];               /* camera::matrix row-major, scene/camera.hpp:11 */
+    float background[3];            /* settings::background_color */
+    int32_t width, height;          /* settings::image_width/height */
+    int32_t bucket_size;            /* settings::bucket_size (default 64, loader.hpp:48) */
+} rtk_scene_desc;
+
+typedef struct {
+    int32_t n_meshes, n_materials, n_lights;
+    int32_t n_vertices, n_triangles;
+    int32_t width, height, bucket_size;
+} rtk_scene_info;
+
+/* template parameters of kd_tree_simd_accel (kd_tree_simd.hpp:63-67) as runtime values */
+typedef struct {
+    int32_t max_depth;              /* 8  */
+    int32_t max_leaf_size;          /* 64 */
+    float eps;                      /* 1e-6f  (config.hpp:8) */
+    int32_t normalize_hit_normal;   /* 1 = kd_tree_simd.hpp:250 behaviour, 0 = kd_tree.hpp:140 behaviour */
+    int32_t device;                 /* HIP device ordinal; -1 = current device */
+} rtk_accel_params;
+
+typedef struct {
+    int32_t n_nodes, n_inner, n_leaves;
+    int32_t n_leaf_refs;            /* unpadded triangle references over all leaves */
+    int32_t max_leaf_refs;
+    int32_t n_triangles;
+    int32_t tree_depth;
+    int32_t reserved;
+} rtk_tree_info;
+
+/* ray3<F> without the derived inv_direction (core/math/ray3.hpp:5-15); 24 bytes */
+typedef struct { float origin[3]; float direction[3]; } rtk_ray;
+
+/* compact hit<F> (render/hit.hpp:9-21); 32 bytes.  Miss: t = -1, tri = mesh = 0xFFFFFFFF.
+ * position = origin + t*direction, w = 1-u-v, face_normal/uvs = triangles[tri] — all derivable by the caller. */
+typedef struct {
+    float t, u, v;
+    uint32_t tri;                   /* global triangle index (position in the concatenated mesh order, kd_tree_simd.hpp:103-111) */
+    uint32_t mesh;                  /* hit<F>::mesh_idx */
+    float normal[3];                /* hit<F>::hit_normal */
+} rtk_hit;
+
+/* config.hpp:6-17 as runtime parameters + multi-GPU tile sharding */
+typedef struct {
+    int32_t width, height;          /* 0 = take from the scene */
+    int32_t spp;                    /* samples_per_pixel */
+    int32_t max_ray_depth;          /* max_ray_depth */
+    int32_t diffuse_rays;           /* diffuse_reflection_ray_count */
+    uint32_t seed;                  /* fixed_rng_seed */
+    double fov_degrees;             /* fov_degrees */
+    float shadow_bias, reflection_bias, refraction_bias;
+    int32_t trace_mode;             /* RTK_TRACE_* */
+    int32_t rank, world_size;       /* bucket i is rendered by rank i % world_size; world_size <= 1: whole frame */
+    int32_t collect_stats;          /* 1 = also count nodes/leaves/triangles per ray (slower kernel variant) */
+} rtk_render_params;
+
+typedef struct {
+    uint64_t rays;                  /* intersect() invocations (primary + shadow segments + reflection + refraction + GI) */
+    uint64_t primary;               /* camera rays */
+    uint64_t hits;                  /* valid only with collect_stats */
+    uint64_t nodes;                 /* tree nodes popped, per ray, summed           (collect_stats) */
+    uint64_t boxpass;               /* nodes whose slab test passed                 (collect_stats) */
+    uint64_t leaves;                /* leaves entered                               (collect_stats) */
+    uint64_t tris;                  /* unpadded triangles tested                    (collect_stats) */
+    uint64_t packets16;             /* = sum ceil(leaf_count/16): W=16 packets the reference would test (collect_stats) */
+} rtk_counters;
+
+/* ---- library ---- */
+int rtk_abi_version(void);
+const char *rtk_last_error(void);               /* thread-local message for the last non-OK status */
+int rtk_device_count(int *count);               /* number of usable HIP devices (0 is not an error) */
+
+/* ---- scene: replaces parse_scene_file + scene<F> ---- */
+int rtk_scene_create(const rtk_scene_desc *desc, rtk_scene **out);      /* copies everything it needs */
+int rtk_scene_load_crtscene(const char *path, rtk_scene **out);         /* io/json/loader.hpp:235-265 */
+int rtk_scene_get_info(const rtk_scene *scene, rtk_scene_info *info);
+/* copies the flattened arrays back out (sizes from rtk_scene_get_info); any pointer may be NULL */
+int rtk_scene_get_arrays(const rtk_scene *scene, int32_t *mesh_material, int32_t *mesh_nverts, int32_t *mesh_ntris,
+                         float *vertices, uint32_t *indices, int32_t *mat_kind, float *mat_albedo, float *mat_ior,
+                         int32_t *mat_smooth, float *light_pos, float *light_intensity, float *cam_pos,
+                         float *cam_mat, float *background);
+/* mesh_object::vertex_normals (scene/object/mesh.hpp:25-43), [nverts of that mesh][3] */
+int rtk_scene_vertex_normals(const rtk_scene *scene, int32_t mesh, float *out);
+void rtk_scene_destroy(rtk_scene *scene);
+
+/* ---- accel: replaces kd_tree_simd_accel ctor + build_tree (kd_tree_simd.hpp:100-185) ---- */
+int rtk_accel_build(const rtk_scene *scene, const rtk_accel_params *params, rtk_accel **out);
+int rtk_accel_tree_info(const rtk_accel *accel, rtk_tree_info *info);
+/* Tree in the REFERENCE's node order (creation order).  nodes_box [n][6] = min xyz, max xyz;
+ * nodes_link [n][4] = child0, child1, leaf_start (index into leaf_refs, -1 for inner), leaf_count;
+ * leaf_refs [n_leaf_refs] global triangle indices in leaf order (the unpadded packet contents). */
+int rtk_accel_tree_dump(const rtk_accel *accel, float *nodes_box, int32_t *nodes_link, int32_t *leaf_refs);
+void rtk_accel_destroy(rtk_accel *accel);
+
+/* ---- batched closest hit: replaces accel.template intersect<cull>(ray) (render/accel/accel.hpp:8-12,
+ *      kd_tree_simd.hpp:187-264); one ray per lane ---- */
+int rtk_accel_intersect(rtk_accel *accel, const rtk_ray *rays, size_t n, int cull, int trace_mode,
+                        rtk_hit *out);                                   /* host buffers, synchronous */
+int rtk_accel_intersect_device(rtk_accel *accel, const rtk_ray *d_rays, size_t n, int cull, int trace_mode,
+                               rtk_hit *d_out, void *hip_stream);        /* device buffers, stream-ordered */
+/* same launch with per-ray work counters accumulated into *counters (device side, synchronous) */
+int rtk_accel_intersect_stats(rtk_accel *accel, const rtk_ray *d_rays, size_t n, int cull, int trace_mode,
+                              rtk_hit *d_out, rtk_counters *counters);
+
+/* ---- frame: replaces render_frame<A,F> (render/render.hpp:18-108) with color_hit/is_occluded device-side ---- */
+/* number of floats the (rank-local) output of rtk_render_frame_device holds */
+int rtk_render_output_floats(const rtk_accel *accel, const rtk_render_params *p, size_t *n_floats);
+int rtk_render_frame(rtk_accel *accel, const rtk_render_params *p, float *rgb /* host [h][w][3] */,
+                     rtk_counters *counters /* may be NULL */);
+/* world_size <= 1: d_out is the frame [h][w][3].  world_size > 1: d_out is this rank's compact bucket
+ * buffer [buckets_per_rank][bucket][bucket][3] (equal length on every rank, ready for an all-gather). */
+int rtk_render_frame_device(rtk_accel *accel, const rtk_render_params *p, float *d_out, void *hip_stream);
+/* counters of the most recent rtk_render_frame_device on this accel; synchronises the stream it ran on */
+int rtk_render_last_counters(rtk_accel *accel, rtk_counters *counters);
+/* after the all-gather: d_gathered = [world][buckets_per_rank][bucket][bucket][3] -> d_rgb [h][w][3] */
+int rtk_tiles_assemble_device(const rtk_accel *accel, const rtk_render_params *p, const float *d_gathered,
+                              float *d_rgb, void *hip_stream);
+
+/* ---- image out: replaces write_ppm (io/image/ppm.hpp:7-25) ---- */
+int rtk_write_ppm(const float *rgb, int32_t width, int32_t height, const char *path);
+/* returns the byte count in *n; writes at most cap bytes into buf (buf may be NULL to query) */
+int rtk_format_ppm(const float *rgb, int32_t width, int32_t height, char *buf, size_t cap, size_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTK_H */

@@ -1,0 +1,506 @@
+// C-ABI of the rtk engine (include/rtk.h).  Owns device buffers, validates operands against what the
+// kernels and their grids assume, and never lets an exception cross the boundary.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "kernels.hpp"
+
+namespace rtk {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+namespace {
+
+int fail(int code, const std::string &msg) { set_error(msg); return code; }
+
+int hip_fail(hipError_t e, const char *what) {
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return RTK_ERR_HIP;
+}
+
+#define RTK_HIP(call)                                        \
+    do {                                                     \
+        const hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);    \
+    } while (0)
+
+template <typename T>
+int upload(const std::vector<T> &src, T **dst) {
+    *dst = nullptr;
+    const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(dst), bytes));
+    if (!src.empty()) RTK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RTK_OK;
+}
+
+}  // namespace
+}  // namespace rtk
+
+struct rtk_accel {
+    rtk_scene scene;                  // private copy: the caller may free its scene (kd_tree_simd.hpp:106-107 copies too)
+    rtk::HostTree tree;
+    rtk_accel_params params;
+    bool has_refractive = false;
+    // device residency (lazy: built on first compute call so host-only use needs no GPU)
+    bool on_device = false;
+    int device = -1;
+    rtk::DevNode *d_nodes = nullptr;
+    rtk::DevTri *d_tris = nullptr;
+    uint32_t *d_tri_ids = nullptr;
+    rtk::DevShade *d_shade = nullptr;
+    rtk::DevMaterial *d_materials = nullptr;
+    rtk::DevLight *d_lights = nullptr;
+    unsigned long long *d_counters = nullptr;     // 8 x u64, rtk_counters order
+    hipStream_t last_stream = nullptr;
+    uint64_t last_primary = 0;
+    bool last_stats = false;
+    std::mutex mu;
+};
+
+namespace rtk {
+namespace {
+
+int ensure_device(rtk_accel *a) {
+    if (a->on_device) {
+        RTK_HIP(hipSetDevice(a->device));
+        return RTK_OK;
+    }
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(RTK_ERR_NO_DEVICE, "no usable HIP device (this engine has no CPU path)");
+    int dev = a->params.device;
+    if (dev < 0) RTK_HIP(hipGetDevice(&dev));
+    if (dev >= count) return fail(RTK_ERR_INVALID, "device ordinal out of range");
+    RTK_HIP(hipSetDevice(dev));
+    a->device = dev;
+    int rc;
+    if ((rc = upload(a->tree.dev_nodes, &a->d_nodes)) != RTK_OK) return rc;
+    if ((rc = upload(a->tree.dev_tris, &a->d_tris)) != RTK_OK) return rc;
+    if ((rc = upload(a->tree.dev_tri_ids, &a->d_tri_ids)) != RTK_OK) return rc;
+    if ((rc = upload(a->tree.dev_shade, &a->d_shade)) != RTK_OK) return rc;
+    if ((rc = upload(a->scene.materials, &a->d_materials)) != RTK_OK) return rc;
+    if ((rc = upload(a->scene.lights, &a->d_lights)) != RTK_OK) return rc;
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->d_counters), 8 * sizeof(unsigned long long)));
+    RTK_HIP(hipMemset(a->d_counters, 0, 8 * sizeof(unsigned long long)));
+    a->on_device = true;
+    return RTK_OK;
+}
+
+dev::TreeView tree_view(const rtk_accel *a) {
+    dev::TreeView t;
+    t.nodes = a->d_nodes; t.tris = a->d_tris; t.tri_ids = a->d_tri_ids; t.shade = a->d_shade;
+    t.n_nodes = static_cast<uint32_t>(a->tree.dev_nodes.size());
+    t.eps = a->params.eps;
+    t.normalize = a->params.normalize_hit_normal;
+    return t;
+}
+
+bool valid_mode(int m) { return m == RTK_TRACE_AUTO || m == RTK_TRACE_LANE || m == RTK_TRACE_WAVE; }
+
+struct FrameGeom {
+    uint32_t width, height, bucket, tiles_x, tiles_y, n_buckets, blocks_side, buckets_per_rank;
+    int rank, world;
+};
+
+int frame_geom(const rtk_accel *a, const rtk_render_params *p, FrameGeom &g) {
+    if (!a || !p) return fail(RTK_ERR_INVALID, "null accel or params");
+    const int64_t w = p->width > 0 ? p->width : a->scene.width;
+    const int64_t h = p->height > 0 ? p->height : a->scene.height;
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536) return fail(RTK_ERR_INVALID, "image size must be in [1, 65536]");
+    if (p->spp < 1) return fail(RTK_ERR_INVALID, "spp must be >= 1");
+    if (p->max_ray_depth < 0 || p->max_ray_depth > kMaxRayDepth)
+        return fail(RTK_ERR_INVALID, "max_ray_depth must be in [0, 16]");
+    if (p->diffuse_rays < 0 || p->diffuse_rays > 32767) return fail(RTK_ERR_INVALID, "diffuse_rays must be in [0, 32767]");
+    if (!valid_mode(p->trace_mode)) return fail(RTK_ERR_INVALID, "unknown trace_mode");
+    g.world = p->world_size > 1 ? p->world_size : 1;
+    g.rank = p->world_size > 1 ? p->rank : 0;
+    if (g.rank < 0 || g.rank >= g.world) return fail(RTK_ERR_INVALID, "rank must be in [0, world_size)");
+    g.width = uint32_t(w); g.height = uint32_t(h);
+    g.bucket = uint32_t(a->scene.bucket_size > 0 ? a->scene.bucket_size : 64);
+    g.tiles_x = (g.width + g.bucket - 1) / g.bucket;
+    g.tiles_y = (g.height + g.bucket - 1) / g.bucket;
+    g.n_buckets = g.tiles_x * g.tiles_y;
+    g.blocks_side = (g.bucket + 7) / 8;
+    g.buckets_per_rank = (g.n_buckets + uint32_t(g.world) - 1) / uint32_t(g.world);
+    return RTK_OK;
+}
+
+}  // namespace
+}  // namespace rtk
+
+using namespace rtk;
+
+extern "C" {
+
+int rtk_abi_version(void) { return RTK_ABI_VERSION; }
+
+const char *rtk_last_error(void) { return g_last_error.c_str(); }
+
+int rtk_device_count(int *count) {
+    if (!count) return fail(RTK_ERR_INVALID, "null count");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return RTK_OK;
+}
+
+// ---------------------------------------------------------------- scene
+
+int rtk_scene_create(const rtk_scene_desc *desc, rtk_scene **out) {
+    if (!desc || !out) return fail(RTK_ERR_INVALID, "null desc or out");
+    *out = nullptr;
+    try {
+        rtk_scene *s = new rtk_scene();
+        std::string err;
+        const int rc = scene_from_desc(*desc, *s, err);
+        if (rc != RTK_OK) { delete s; return fail(rc, err); }
+        *out = s;
+        return RTK_OK;
+    } catch (const std::exception &e) { return fail(RTK_ERR_INVALID, e.what()); }
+}
+
+int rtk_scene_load_crtscene(const char *path, rtk_scene **out) {
+    if (!path || !out) return fail(RTK_ERR_INVALID, "null path or out");
+    *out = nullptr;
+    try {
+        rtk_scene *s = new rtk_scene();
+        std::string err;
+        const int rc = scene_from_crtscene(path, *s, err);
+        if (rc != RTK_OK) { delete s; return fail(rc, err); }
+        *out = s;
+        return RTK_OK;
+    } catch (const std::exception &e) { return fail(RTK_ERR_INVALID, e.what()); }
+}
+
+int rtk_scene_get_info(const rtk_scene *s, rtk_scene_info *info) {
+    if (!s || !info) return fail(RTK_ERR_INVALID, "null scene or info");
+    info->n_meshes = int32_t(s->meshes.size());
+    info->n_materials = int32_t(s->materials.size());
+    info->n_lights = int32_t(s->lights.size());
+    info->n_vertices = s->n_vertices;
+    info->n_triangles = s->n_triangles;
+    info->width = s->width; info->height = s->height; info->bucket_size = s->bucket_size;
+    return RTK_OK;
+}
+
+int rtk_scene_get_arrays(const rtk_scene *s, int32_t *mesh_material, int32_t *mesh_nverts, int32_t *mesh_ntris,
+                         float *vertices, uint32_t *indices, int32_t *mat_kind, float *mat_albedo, float *mat_ior,
+                         int32_t *mat_smooth, float *light_pos, float *light_intensity, float *cam_pos, float *cam_mat,
+                         float *background) {
+    if (!s) return fail(RTK_ERR_INVALID, "null scene");
+    size_t vo = 0, to = 0;
+    for (size_t m = 0; m < s->meshes.size(); ++m) {
+        const HostMesh &hm = s->meshes[m];
+        if (mesh_material) mesh_material[m] = hm.material;
+        if (mesh_nverts) mesh_nverts[m] = int32_t(hm.vertices.size());
+        if (mesh_ntris) mesh_ntris[m] = int32_t(hm.indices.size() / 3);
+        if (vertices) for (size_t i = 0; i < hm.vertices.size(); ++i) {
+            vertices[(vo + i) * 3] = hm.vertices[i].x; vertices[(vo + i) * 3 + 1] = hm.vertices[i].y; vertices[(vo + i) * 3 + 2] = hm.vertices[i].z;
+        }
+        if (indices && !hm.indices.empty()) std::memcpy(indices + to * 3, hm.indices.data(), hm.indices.size() * sizeof(uint32_t));
+        vo += hm.vertices.size(); to += hm.indices.size() / 3;
+    }
+    for (size_t i = 0; i < s->materials.size(); ++i) {
+        if (mat_kind) mat_kind[i] = s->materials[i].kind;
+        if (mat_albedo) std::memcpy(mat_albedo + i * 3, s->materials[i].albedo, 3 * sizeof(float));
+        if (mat_ior) mat_ior[i] = s->materials[i].ior;
+        if (mat_smooth) mat_smooth[i] = s->materials[i].smooth;
+    }
+    for (size_t i = 0; i < s->lights.size(); ++i) {
+        if (light_pos) std::memcpy(light_pos + i * 3, s->lights[i].pos, 3 * sizeof(float));
+        if (light_intensity) light_intensity[i] = s->lights[i].intensity;
+    }
+    if (cam_pos) std::memcpy(cam_pos, s->cam_pos, sizeof(s->cam_pos));
+    if (cam_mat) std::memcpy(cam_mat, s->cam_mat, sizeof(s->cam_mat));
+    if (background) std::memcpy(background, s->background, sizeof(s->background));
+    return RTK_OK;
+}
+
+int rtk_scene_vertex_normals(const rtk_scene *s, int32_t mesh, float *out) {
+    if (!s || !out) return fail(RTK_ERR_INVALID, "null scene or out");
+    if (mesh < 0 || size_t(mesh) >= s->meshes.size()) return fail(RTK_ERR_INVALID, "mesh index out of range");
+    const HostMesh &hm = s->meshes[size_t(mesh)];
+    for (size_t i = 0; i < hm.vertex_normals.size(); ++i) {
+        out[i * 3] = hm.vertex_normals[i].x; out[i * 3 + 1] = hm.vertex_normals[i].y; out[i * 3 + 2] = hm.vertex_normals[i].z;
+    }
+    return RTK_OK;
+}
+
+void rtk_scene_destroy(rtk_scene *s) { delete s; }
+
+// ---------------------------------------------------------------- accel
+
+int rtk_accel_build(const rtk_scene *scene, const rtk_accel_params *params, rtk_accel **out) {
+    if (!scene || !out) return fail(RTK_ERR_INVALID, "null scene or out");
+    *out = nullptr;
+    try {
+        rtk_accel *a = new rtk_accel();
+        a->scene = *scene;
+        if (params) a->params = *params;
+        else { a->params.max_depth = 8; a->params.max_leaf_size = 64; a->params.eps = 1e-6f; a->params.normalize_hit_normal = 1; a->params.device = -1; }
+        std::string err;
+        const int rc = build_tree(a->scene, a->params.max_depth, a->params.max_leaf_size, a->tree, err);
+        if (rc != RTK_OK) { delete a; return fail(rc, err); }
+        if (a->tree.dev_nodes.size() > 0x7FFFFFFFull || a->tree.dev_tris.size() > 0x7FFFFFFFull) {
+            delete a; return fail(RTK_ERR_INVALID, "tree too large for 32-bit node/triangle indices");
+        }
+        for (const DevMaterial &m : a->scene.materials) if (m.kind == RTK_MAT_REFRACTIVE) a->has_refractive = true;
+        *out = a;
+        return RTK_OK;
+    } catch (const std::exception &e) { return fail(RTK_ERR_INVALID, e.what()); }
+}
+
+int rtk_accel_tree_info(const rtk_accel *a, rtk_tree_info *info) {
+    if (!a || !info) return fail(RTK_ERR_INVALID, "null accel or info");
+    std::memset(info, 0, sizeof(*info));
+    info->n_nodes = int32_t(a->tree.nodes.size());
+    for (const HostNode &n : a->tree.nodes) {
+        if (n.leaf_start >= 0) { info->n_leaves += 1; if (n.leaf_count > info->max_leaf_refs) info->max_leaf_refs = n.leaf_count; }
+        else info->n_inner += 1;
+    }
+    info->n_leaf_refs = int32_t(a->tree.leaf_refs.size());
+    info->n_triangles = int32_t(a->tree.triangles.size());
+    info->tree_depth = a->tree.depth;
+    return RTK_OK;
+}
+
+int rtk_accel_tree_dump(const rtk_accel *a, float *nodes_box, int32_t *nodes_link, int32_t *leaf_refs) {
+    if (!a) return fail(RTK_ERR_INVALID, "null accel");
+    for (size_t i = 0; i < a->tree.nodes.size(); ++i) {
+        const HostNode &n = a->tree.nodes[i];
+        if (nodes_box) {
+            float *b = nodes_box + i * 6;
+            b[0] = n.box.mn.x; b[1] = n.box.mn.y; b[2] = n.box.mn.z; b[3] = n.box.mx.x; b[4] = n.box.mx.y; b[5] = n.box.mx.z;
+        }
+        if (nodes_link) {
+            int32_t *l = nodes_link + i * 4;
+            l[0] = n.child0; l[1] = n.child1; l[2] = n.leaf_start; l[3] = n.leaf_count;
+        }
+    }
+    if (leaf_refs && !a->tree.leaf_refs.empty())
+        std::memcpy(leaf_refs, a->tree.leaf_refs.data(), a->tree.leaf_refs.size() * sizeof(int32_t));
+    return RTK_OK;
+}
+
+void rtk_accel_destroy(rtk_accel *a) {
+    if (!a) return;
+    if (a->on_device) {
+        (void)hipSetDevice(a->device);
+        (void)hipFree(a->d_nodes); (void)hipFree(a->d_tris); (void)hipFree(a->d_tri_ids); (void)hipFree(a->d_shade);
+        (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
+    }
+    delete a;
+}
+
+// ---------------------------------------------------------------- batched intersect
+
+static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, int cull, int mode, rtk_hit *d_out,
+                                 hipStream_t s, bool stats) {
+    if (!valid_mode(mode)) return fail(RTK_ERR_INVALID, "unknown trace_mode");
+    if (n > (size_t(1) << 38)) return fail(RTK_ERR_INVALID, "too many rays for one launch");
+    if (n > 0 && (!d_rays || !d_out)) return fail(RTK_ERR_INVALID, "null ray or hit buffer");
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) return fail(RTK_ERR_INVALID, "hit buffer must be 16-byte aligned");
+    dev::IntersectArgs A;
+    A.tree = tree_view(a);
+    A.rays = d_rays; A.out = d_out; A.n = n; A.cull = cull ? 1 : 0; A.counters = a->d_counters;
+    const hipError_t e = launch_intersect(A, mode, stats, s);
+    if (e != hipSuccess) return hip_fail(e, "launch k_intersect");
+    return RTK_OK;
+}
+
+int rtk_accel_intersect_device(rtk_accel *a, const rtk_ray *d_rays, size_t n, int cull, int mode, rtk_hit *d_out, void *stream) {
+    if (!a) return fail(RTK_ERR_INVALID, "null accel");
+    std::lock_guard<std::mutex> lock(a->mu);
+    const int rc = ensure_device(a);
+    if (rc != RTK_OK) return rc;
+    return intersect_device_impl(a, d_rays, n, cull, mode, d_out, static_cast<hipStream_t>(stream), false);
+}
+
+int rtk_accel_intersect_stats(rtk_accel *a, const rtk_ray *d_rays, size_t n, int cull, int mode, rtk_hit *d_out,
+                              rtk_counters *counters) {
+    if (!a || !counters) return fail(RTK_ERR_INVALID, "null accel or counters");
+    std::lock_guard<std::mutex> lock(a->mu);
+    int rc = ensure_device(a);
+    if (rc != RTK_OK) return rc;
+    RTK_HIP(hipMemsetAsync(a->d_counters, 0, 8 * sizeof(unsigned long long), nullptr));
+    rc = intersect_device_impl(a, d_rays, n, cull, mode, d_out, nullptr, true);
+    if (rc != RTK_OK) return rc;
+    unsigned long long h[8];
+    RTK_HIP(hipMemcpy(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    counters->rays = h[0]; counters->primary = 0; counters->hits = h[2]; counters->nodes = h[3]; counters->boxpass = h[4];
+    counters->leaves = h[5]; counters->tris = h[6]; counters->packets16 = h[7];
+    return RTK_OK;
+}
+
+int rtk_accel_intersect(rtk_accel *a, const rtk_ray *rays, size_t n, int cull, int mode, rtk_hit *out) {
+    if (!a) return fail(RTK_ERR_INVALID, "null accel");
+    if (n > 0 && (!rays || !out)) return fail(RTK_ERR_INVALID, "null ray or hit buffer");
+    std::lock_guard<std::mutex> lock(a->mu);
+    int rc = ensure_device(a);
+    if (rc != RTK_OK) return rc;
+    if (n == 0) return RTK_OK;
+    rtk_ray *d_rays = nullptr;
+    rtk_hit *d_out = nullptr;
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&d_rays), n * sizeof(rtk_ray)));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_out), n * sizeof(rtk_hit));
+    if (e != hipSuccess) { (void)hipFree(d_rays); return hip_fail(e, "hipMalloc hits"); }
+    e = hipMemcpy(d_rays, rays, n * sizeof(rtk_ray), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = intersect_device_impl(a, d_rays, n, cull, mode, d_out, nullptr, false);
+        if (rc == RTK_OK) e = hipMemcpy(out, d_out, n * sizeof(rtk_hit), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_rays); (void)hipFree(d_out);
+    if (rc != RTK_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "intersect copy");
+    return RTK_OK;
+}
+
+// ---------------------------------------------------------------- frame
+
+int rtk_render_output_floats(const rtk_accel *a, const rtk_render_params *p, size_t *n_floats) {
+    if (!n_floats) return fail(RTK_ERR_INVALID, "null n_floats");
+    FrameGeom g;
+    const int rc = frame_geom(a, p, g);
+    if (rc != RTK_OK) return rc;
+    *n_floats = (g.world > 1) ? size_t(g.buckets_per_rank) * g.bucket * g.bucket * 3 : size_t(g.width) * g.height * 3;
+    return RTK_OK;
+}
+
+static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d_out, hipStream_t s) {
+    FrameGeom g;
+    int rc = frame_geom(a, p, g);
+    if (rc != RTK_OK) return rc;
+    if (!d_out) return fail(RTK_ERR_INVALID, "null output buffer");
+    dev::RenderArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.tree = tree_view(a);
+    A.materials = a->d_materials; A.lights = a->d_lights;
+    A.n_lights = int(a->scene.lights.size());
+    A.has_refractive = a->has_refractive ? 1 : 0;
+    std::memcpy(A.cam_pos, a->scene.cam_pos, sizeof(A.cam_pos));
+    std::memcpy(A.cam_mat, a->scene.cam_mat, sizeof(A.cam_mat));
+    std::memcpy(A.background, a->scene.background, sizeof(A.background));
+    A.width = g.width; A.height = g.height;
+    A.aspect = static_cast<float>(g.width) / static_cast<float>(g.height);                    // render.hpp:26
+    const double fov_radians = p->fov_degrees * (3.14159265358979323846 / 180.0);             // utils/convert.hpp:4-6
+    A.tan_half_fov = std::tan(fov_radians / static_cast<double>(2.0f));                       // render.hpp:55-57
+    A.spp = p->spp; A.max_depth = p->max_ray_depth; A.diffuse_rays = p->diffuse_rays; A.seed = p->seed;
+    A.shadow_bias = p->shadow_bias; A.reflection_bias = p->reflection_bias; A.refraction_bias = p->refraction_bias;
+    A.bucket = g.bucket; A.tiles_x = g.tiles_x; A.tiles_y = g.tiles_y; A.n_buckets = g.n_buckets;
+    A.blocks_per_bucket_side = g.blocks_side; A.buckets_per_rank = g.buckets_per_rank;
+    A.rank = g.rank; A.world = g.world; A.compact = g.world > 1 ? 1 : 0;
+    A.out = d_out; A.counters = a->d_counters;
+    const bool forks = a->has_refractive || p->diffuse_rays > 0;
+    RTK_HIP(hipMemsetAsync(a->d_counters, 0, 8 * sizeof(unsigned long long), s));
+    if (g.world > 1) {
+        // buckets past the end of the frame (padding so that every rank has equal length) stay zero
+        size_t nf = size_t(g.buckets_per_rank) * g.bucket * g.bucket * 3;
+        RTK_HIP(hipMemsetAsync(d_out, 0, nf * sizeof(float), s));
+    }
+    const hipError_t e = launch_render(A, p->trace_mode, p->collect_stats != 0, forks, s);
+    if (e != hipSuccess) return hip_fail(e, "launch k_render");
+    a->last_stream = s;
+    a->last_stats = p->collect_stats != 0;
+    // primary rays of this rank: pixels of its buckets x spp
+    uint64_t pixels = 0;
+    for (uint32_t b = uint32_t(g.rank); b < g.n_buckets; b += uint32_t(g.world)) {
+        const uint32_t bx = (b % g.tiles_x) * g.bucket, by = (b / g.tiles_x) * g.bucket;
+        const uint32_t w = (bx + g.bucket <= g.width) ? g.bucket : g.width - bx;
+        const uint32_t h = (by + g.bucket <= g.height) ? g.bucket : g.height - by;
+        pixels += uint64_t(w) * h;
+    }
+    a->last_primary = pixels * uint64_t(p->spp);
+    return RTK_OK;
+}
+
+int rtk_render_frame_device(rtk_accel *a, const rtk_render_params *p, float *d_out, void *stream) {
+    if (!a || !p) return fail(RTK_ERR_INVALID, "null accel or params");
+    std::lock_guard<std::mutex> lock(a->mu);
+    const int rc = ensure_device(a);
+    if (rc != RTK_OK) return rc;
+    return render_device_impl(a, p, d_out, static_cast<hipStream_t>(stream));
+}
+
+int rtk_render_last_counters(rtk_accel *a, rtk_counters *c) {
+    if (!a || !c) return fail(RTK_ERR_INVALID, "null accel or counters");
+    std::lock_guard<std::mutex> lock(a->mu);
+    if (!a->on_device) return fail(RTK_ERR_INVALID, "no frame has been rendered on this accel");
+    RTK_HIP(hipSetDevice(a->device));
+    RTK_HIP(hipStreamSynchronize(a->last_stream));
+    unsigned long long h[8];
+    RTK_HIP(hipMemcpy(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    std::memset(c, 0, sizeof(*c));
+    c->rays = h[0]; c->primary = a->last_primary;
+    if (a->last_stats) { c->hits = h[2]; c->nodes = h[3]; c->boxpass = h[4]; c->leaves = h[5]; c->tris = h[6]; c->packets16 = h[7]; }
+    return RTK_OK;
+}
+
+int rtk_render_frame(rtk_accel *a, const rtk_render_params *p, float *rgb, rtk_counters *counters) {
+    if (!a || !p || !rgb) return fail(RTK_ERR_INVALID, "null accel, params or rgb");
+    if (p->world_size > 1) return fail(RTK_ERR_INVALID, "rtk_render_frame renders whole frames; use rtk_render_frame_device for sharded output");
+    size_t nf = 0;
+    int rc = rtk_render_output_floats(a, p, &nf);
+    if (rc != RTK_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lock(a->mu);
+        rc = ensure_device(a);
+        if (rc != RTK_OK) return rc;
+        float *d_out = nullptr;
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&d_out), nf * sizeof(float)));
+        rc = render_device_impl(a, p, d_out, nullptr);
+        hipError_t e = hipSuccess;
+        if (rc == RTK_OK) e = hipMemcpy(rgb, d_out, nf * sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipFree(d_out);
+        if (rc != RTK_OK) return rc;
+        if (e != hipSuccess) return hip_fail(e, "frame copy");
+    }
+    if (counters) return rtk_render_last_counters(a, counters);
+    return RTK_OK;
+}
+
+int rtk_tiles_assemble_device(const rtk_accel *a, const rtk_render_params *p, const float *d_gathered, float *d_rgb, void *stream) {
+    FrameGeom g;
+    const int rc = frame_geom(a, p, g);
+    if (rc != RTK_OK) return rc;
+    if (!d_gathered || !d_rgb) return fail(RTK_ERR_INVALID, "null buffer");
+    dev::AssembleArgs A;
+    A.gathered = d_gathered; A.rgb = d_rgb; A.width = g.width; A.height = g.height; A.bucket = g.bucket;
+    A.tiles_x = g.tiles_x; A.world = uint32_t(g.world); A.buckets_per_rank = g.buckets_per_rank;
+    const hipError_t e = launch_assemble(A, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "launch k_assemble");
+    return RTK_OK;
+}
+
+// ---------------------------------------------------------------- image out
+
+int rtk_format_ppm(const float *rgb, int32_t width, int32_t height, char *buf, size_t cap, size_t *n) {
+    if (!rgb || !n || width <= 0 || height <= 0) return fail(RTK_ERR_INVALID, "bad image");
+    try {
+        const std::string s = format_ppm(rgb, width, height);
+        *n = s.size();
+        if (buf) std::memcpy(buf, s.data(), s.size() < cap ? s.size() : cap);
+        return RTK_OK;
+    } catch (const std::exception &e) { return fail(RTK_ERR_INVALID, e.what()); }
+}
+
+int rtk_write_ppm(const float *rgb, int32_t width, int32_t height, const char *path) {
+    if (!rgb || !path || width <= 0 || height <= 0) return fail(RTK_ERR_INVALID, "bad image or path");
+    try {
+        const std::string s = format_ppm(rgb, width, height);
+        std::FILE *f = std::fopen(path, "wb");
+        if (!f) return fail(RTK_ERR_IO, std::string("cannot open ") + path);
+        const size_t w = std::fwrite(s.data(), 1, s.size(), f);
+        const int c = std::fclose(f);
+        if (w != s.size() || c != 0) return fail(RTK_ERR_IO, std::string("short write to ") + path);
+        return RTK_OK;
+    } catch (const std::exception &e) { return fail(RTK_ERR_INVALID, e.what()); }
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// .crtscene reader: a small JSON DOM + the mapping of io/json/loader.hpp:46-265 onto rtk_scene.
+// The reference parses with simdjson (absent offline); numbers take the same double -> float path
+// (loader.hpp:9-17) via strtod, which is correctly rounded like simdjson's parser.
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "rtk_internal.hpp"
+
+namespace rtk {
+
+int finish_mesh(HostMesh &m, std::string &err);   // scene.cpp
+
+namespace {
+
+struct JValue;
+using JPtr = std::unique_ptr<JValue>;
+
+struct JValue {
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    bool b = false;
+    double num = 0.0;
+    std::string str;
+    std::vector<JPtr> arr;
+    std::vector<std::pair<std::string, JPtr>> obj;
+
+    const JValue *get(const char *key) const {
+        if (kind != Object) return nullptr;
+        for (const auto &kv : obj) if (kv.first == key) return kv.second.get();
+        return nullptr;
+    }
+};
+
+struct Parser {
+    const char *p, *end;
+    std::string err;
+
+    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; }
+    bool fail(const char *m) { if (err.empty()) err = m; return false; }
+
+    bool string(std::string &out) {
+        if (p >= end || *p != '"') return fail("expected string");
+        ++p;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= end) return fail("bad escape");
+                switch (*p) {
+                    case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+                    case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                    case 'u': {  // keep BMP code points as UTF-8; scene files only use ASCII
+                        if (end - p < 5) return fail("bad \\u escape");
+                        unsigned cp = 0;
+                        for (int i = 1; i <= 4; ++i) {
+                            const char c = p[i];
+                            cp <<= 4;
+                            if (c >= '0' && c <= '9') cp |= unsigned(c - '0');
+                            else if (c >= 'a' && c <= 'f') cp |= unsigned(c - 'a' + 10);
+                            else if (c >= 'A' && c <= 'F') cp |= unsigned(c - 'A' + 10);
+                            else return fail("bad \\u escape");
+                        }
+                        p += 4;
+                        if (cp < 0x80) out += char(cp);
+                        else if (cp < 0x800) { out += char(0xC0 | (cp >> 6)); out += char(0x80 | (cp & 0x3F)); }
+                        else { out += char(0xE0 | (cp >> 12)); out += char(0x80 | ((cp >> 6) & 0x3F)); out += char(0x80 | (cp & 0x3F)); }
+                        break;
+                    }
+                    default: out += *p; break;
+                }
+                ++p;
+            } else {
+                out += *p++;
+            }
+        }
+        if (p >= end) return fail("unterminated string");
+        ++p;
+        return true;
+    }
+
+    bool value(JValue &v, int depth) {
+        if (depth > 64) return fail("nesting too deep");
+        ws();
+        if (p >= end) return fail("unexpected end of input");
+        const char c = *p;
+        if (c == '{') {
+            v.kind = JValue::Object; ++p; ws();
+            if (p < end && *p == '}') { ++p; return true; }
+            for (;;) {
+                ws();
+                std::string key;
+                if (!string(key)) return false;
+                ws();
+                if (p >= end || *p != ':') return fail("expected ':'");
+                ++p;
+                JPtr child(new JValue);
+                if (!value(*child, depth + 1)) return false;
+                v.obj.emplace_back(std::move(key), std::move(child));
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == '}') { ++p; return true; }
+                return fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            v.kind = JValue::Array; ++p; ws();
+            if (p < end && *p == ']') { ++p; return true; }
+            for (;;) {
+                JPtr child(new JValue);
+                if (!value(*child, depth + 1)) return false;
+                v.arr.push_back(std::move(child));
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == ']') { ++p; return true; }
+                return fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') { v.kind = JValue::String; return string(v.str); }
+        if (end - p >= 4 && !std::strncmp(p, "true", 4)) { v.kind = JValue::Bool; v.b = true; p += 4; return true; }
+        if (end - p >= 5 && !std::strncmp(p, "false", 5)) { v.kind = JValue::Bool; v.b = false; p += 5; return true; }
+        if (end - p >= 4 && !std::strncmp(p, "null", 4)) { v.kind = JValue::Null; p += 4; return true; }
+        if (c == '-' || (c >= '0' && c <= '9')) {
+            char *stop = nullptr;
+            errno = 0;
+            v.num = std::strtod(p, &stop);
+            if (stop == p) return fail("bad number");
+            v.kind = JValue::Number; p = stop;
+            return true;
+        }
+        return fail("unexpected character");
+    }
+};
+
+struct Fail { int code; std::string msg; };
+
+const JValue &need(const JValue *parent, const char *key, JValue::Kind kind, const char *what) {
+    const JValue *v = parent ? parent->get(key) : nullptr;
+    if (!v) throw Fail{RTK_ERR_PARSE, std::string("missing key '") + key + "' in " + what};
+    if (v->kind != kind) throw Fail{RTK_ERR_PARSE, std::string("key '") + key + "' in " + what + " has the wrong type"};
+    return *v;
+}
+
+float f32(const JValue &v, const char *what) {                         // loader.hpp:9-17
+    if (v.kind != JValue::Number) throw Fail{RTK_ERR_PARSE, std::string(what) + ": expected a number"};
+    return static_cast<float>(v.num);
+}
+
+void floats(const JValue &arr, size_t n, float *out, const char *what) { // load_vec3 / load_mat3 / load_color
+    if (arr.arr.size() < n) throw Fail{RTK_ERR_PARSE, std::string(what) + ": array too short"};
+    for (size_t i = 0; i < n; ++i) out[i] = f32(*arr.arr[i], what);
+}
+
+int64_t uint_of(const JValue &v, const char *what) {
+    if (v.kind != JValue::Number || v.num < 0 || v.num != static_cast<double>(static_cast<int64_t>(v.num)))
+        throw Fail{RTK_ERR_PARSE, std::string(what) + ": expected an unsigned integer"};
+    return static_cast<int64_t>(v.num);
+}
+
+}  // namespace
+
+int scene_from_crtscene(const char *path, rtk_scene &out, std::string &err) {
+    std::FILE *f = std::fopen(path, "rb");
+    if (!f) { err = std::string("cannot open ") + path; return RTK_ERR_IO; }
+    std::string text;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, got);
+    std::fclose(f);
+
+    Parser ps{text.data(), text.data() + text.size(), {}};
+    JValue root;
+    if (!ps.value(root, 0)) { err = "JSON: " + ps.err; return RTK_ERR_PARSE; }
+    ps.ws();
+    if (ps.p != ps.end) { err = "JSON: trailing characters"; return RTK_ERR_PARSE; }
+
+    try {
+        // load_settings, loader.hpp:46-60
+        const JValue &settings = need(&root, "settings", JValue::Object, "scene");
+        floats(need(&settings, "background_color", JValue::Array, "settings"), 3, out.background, "background_color");
+        const JValue &img = need(&settings, "image_settings", JValue::Object, "settings");
+        out.width = static_cast<int32_t>(uint_of(need(&img, "width", JValue::Number, "image_settings"), "width"));
+        out.height = static_cast<int32_t>(uint_of(need(&img, "height", JValue::Number, "image_settings"), "height"));
+        out.bucket_size = 64;
+        if (const JValue *bs = img.get("bucket_size")) {
+            if (bs->kind == JValue::Number && bs->num >= 0 && bs->num == static_cast<double>(static_cast<int64_t>(bs->num)))
+                out.bucket_size = static_cast<int32_t>(bs->num);
+        }
+        // load_camera, loader.hpp:62-68
+        const JValue &cam = need(&root, "camera", JValue::Object, "scene");
+        floats(need(&cam, "position", JValue::Array, "camera"), 3, out.cam_pos, "camera.position");
+        floats(need(&cam, "matrix", JValue::Array, "camera"), 9, out.cam_mat, "camera.matrix");
+        // lights, loader.hpp:245-247 (a missing key is an error there too)
+        out.lights.clear();
+        for (const JPtr &l : need(&root, "lights", JValue::Array, "scene").arr) {
+            DevLight dl;
+            floats(need(l.get(), "position", JValue::Array, "light"), 3, dl.pos, "light.position");
+            dl.intensity = f32(need(l.get(), "intensity", JValue::Number, "light"), "light.intensity");
+            out.lights.push_back(dl);
+        }
+        // load_material, loader.hpp:108-147
+        out.materials.clear();
+        for (const JPtr &m : need(&root, "materials", JValue::Array, "scene").arr) {
+            DevMaterial dm;
+            std::memset(&dm, 0, sizeof(dm));
+            dm.ior = 1.0f;
+            const std::string &type = need(m.get(), "type", JValue::String, "material").str;
+            if (type == "diffuse") {
+                const JValue *alb = m->get("albedo");
+                if (!alb) throw Fail{RTK_ERR_PARSE, "missing key 'albedo' in material"};
+                if (alb->kind == JValue::String)
+                    throw Fail{RTK_ERR_UNSUPPORTED, "texture materials are outside the accelerated path"};
+                if (alb->kind != JValue::Array) throw Fail{RTK_ERR_INVALID, "albedo neither array nor string"};
+                dm.kind = RTK_MAT_DIFFUSE;
+                floats(*alb, 3, dm.albedo, "material.albedo");
+            } else if (type == "reflective") {
+                dm.kind = RTK_MAT_REFLECTIVE;
+                floats(need(m.get(), "albedo", JValue::Array, "material"), 3, dm.albedo, "material.albedo");
+            } else if (type == "refractive") {
+                dm.kind = RTK_MAT_REFRACTIVE;
+                dm.ior = f32(need(m.get(), "ior", JValue::Number, "material"), "material.ior");
+            } else if (type == "constant") {
+                dm.kind = RTK_MAT_CONSTANT;
+                floats(need(m.get(), "albedo", JValue::Array, "material"), 3, dm.albedo, "material.albedo");
+            } else {
+                throw Fail{RTK_ERR_INVALID, "material type unknown"};
+            }
+            dm.smooth = need(m.get(), "smooth_shading", JValue::Bool, "material").b ? 1 : 0;
+            out.materials.push_back(dm);
+        }
+        // load_mesh, loader.hpp:149-233
+        out.meshes.clear();
+        out.n_vertices = out.n_triangles = 0;
+        for (const JPtr &o : need(&root, "objects", JValue::Array, "scene").arr) {
+            HostMesh mesh;
+            const int64_t mi = uint_of(need(o.get(), "material_index", JValue::Number, "object"), "material_index");
+            if (mi >= static_cast<int64_t>(out.materials.size())) throw Fail{RTK_ERR_INVALID, "material_index out of range"};
+            mesh.material = static_cast<int32_t>(mi);
+            const JValue &vs = need(o.get(), "vertices", JValue::Array, "object");
+            if (vs.arr.size() % 3) throw Fail{RTK_ERR_INVALID, "vertex coordinates not multiple of 3"};
+            mesh.vertices.resize(vs.arr.size() / 3);
+            for (size_t i = 0; i < mesh.vertices.size(); ++i)
+                mesh.vertices[i] = {f32(*vs.arr[i * 3], "vertices"), f32(*vs.arr[i * 3 + 1], "vertices"), f32(*vs.arr[i * 3 + 2], "vertices")};
+            const JValue &ts = need(o.get(), "triangles", JValue::Array, "object");
+            if (ts.arr.size() % 3) throw Fail{RTK_ERR_INVALID, "triangle indices not multiple of 3"};
+            mesh.indices.resize(ts.arr.size());
+            for (size_t i = 0; i < ts.arr.size(); ++i) mesh.indices[i] = static_cast<uint32_t>(uint_of(*ts.arr[i], "triangles"));
+            std::string merr;
+            const int rc = finish_mesh(mesh, merr);
+            if (rc != RTK_OK) throw Fail{rc, merr};
+            out.n_vertices += static_cast<int32_t>(mesh.vertices.size());
+            out.n_triangles += static_cast<int32_t>(mesh.indices.size() / 3);
+            out.meshes.push_back(std::move(mesh));
+        }
+    } catch (const Fail &fl) {
+        err = std::string(path) + ": " + fl.msg;
+        return fl.code;
+    }
+    return RTK_OK;
+}
+
+}  // namespace rtk

@@ -1,0 +1,497 @@
+// HIP kernels for gfx950: batched closest-hit intersect, the device-side render loop
+// (render_frame / color_hit / is_occluded of render/render.hpp), and the multi-GPU bucket assembly.
+// One ray per lane, 256-thread workgroups (4 wave64), kd-tree nodes staged in LDS.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "trace.hip.hpp"
+
+namespace rtk {
+namespace dev {
+
+// ------------------------------------------------------------------------------------------------
+// node staging: the whole traversal-ordered node array goes to LDS with coalesced 16-byte loads.
+__device__ __forceinline__ void stage_nodes(const DevNode *g_nodes, uint32_t n_nodes, DevNode *lds_nodes) {
+    const float4 *src = reinterpret_cast<const float4 *>(g_nodes);
+    float4 *dst = reinterpret_cast<float4 *>(lds_nodes);
+    for (uint32_t i = threadIdx.x; i < n_nodes * 2u; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void flush_stats(const Stats &st, uint32_t rays, unsigned long long *counters) {
+    // counters: rays, primary, hits, nodes, boxpass, leaves, tris, packets16 (rtk_counters order)
+    const uint32_t r = wave_sum(rays), h = wave_sum(st.hits), nd = wave_sum(st.nodes), bp = wave_sum(st.boxpass),
+                   lv = wave_sum(st.leaves), tr = wave_sum(st.tris), pk = wave_sum(st.packets16);
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(counters + 0, (unsigned long long)r);
+        atomicAdd(counters + 2, (unsigned long long)h);
+        atomicAdd(counters + 3, (unsigned long long)nd);
+        atomicAdd(counters + 4, (unsigned long long)bp);
+        atomicAdd(counters + 5, (unsigned long long)lv);
+        atomicAdd(counters + 6, (unsigned long long)tr);
+        atomicAdd(counters + 7, (unsigned long long)pk);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// accel.intersect<cull>(ray) for a batch (kd_tree_simd.hpp:187-264): lane i takes ray i.
+template <int MODE, bool STATS, bool LDS_NODES>
+__global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
+    if (LDS_NODES) stage_nodes(A.tree.nodes, A.tree.n_nodes, lds_nodes);
+
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < A.n;
+    Ray r;
+    if (active) {
+        const float *p = reinterpret_cast<const float *>(A.rays + i);
+        r = make_ray(mk(p[0], p[1], p[2]), mk(p[3], p[4], p[5]));
+    } else {
+        r = make_ray(mk(0.f, 0.f, 0.f), mk(1.f, 1.f, 1.f));
+    }
+    Stats st = {0, 0, 0, 0, 0, 0};
+    const Cand c = trace<MODE, STATS, LDS_NODES>(A.tree, lds_nodes, r, A.cull != 0, active, st);
+    if (active) {
+        float4 o0, o1;
+        if (c.k != kMiss) {
+            const Surface s = reconstruct(A.tree, c);
+            o0 = make_float4(c.t, c.u, c.v, __uint_as_float(s.tri));
+            o1 = make_float4(__uint_as_float(s.mesh), s.hit_normal.x, s.hit_normal.y, s.hit_normal.z);
+        } else {
+            o0 = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kMiss));
+            o1 = make_float4(__uint_as_float(kMiss), 0.0f, 0.0f, 0.0f);
+        }
+        float4 *out = reinterpret_cast<float4 *>(A.out + i);
+        out[0] = o0;
+        out[1] = o1;
+    }
+    if (STATS) flush_stats(st, active ? 1u : 0u, A.counters);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Counter-based RNG (replaces utils/rand.hpp:5-19, see oracle/rt_oracle.c for the rationale) and the
+// deterministic double-precision sin/cos used for GI directions.  Same integer / IEEE-double operations
+// as the CPU side, so both produce identical bits.
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
+    const uint32_t s = x * 747796405u + 2891336453u;
+    const uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+__device__ __forceinline__ float urand01(uint32_t seed_hash, uint32_t pixel, uint32_t sample, uint32_t counter) {
+    const uint32_t h = pcg_hash(counter + pcg_hash(sample + pcg_hash(pixel + seed_hash)));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __noinline__ void det_sincos(float angle, float &s, float &c) {
+    const double x = (double)angle;
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632673412561417e+00, pio2_lo = 6.07710050650619224932e-11;
+    const double kf = __builtin_floor(x * two_over_pi + 0.5);
+    const double r = (x - kf * pio2_hi) - kf * pio2_lo;
+    const double r2 = r * r;
+    double ps = -1.0 / 1307674368000.0;
+    ps = ps * r2 + 1.0 / 6227020800.0;
+    ps = ps * r2 - 1.0 / 39916800.0;
+    ps = ps * r2 + 1.0 / 362880.0;
+    ps = ps * r2 - 1.0 / 5040.0;
+    ps = ps * r2 + 1.0 / 120.0;
+    ps = ps * r2 - 1.0 / 6.0;
+    const double sr = r + r * (r2 * ps);
+    double pc = 1.0 / 20922789888000.0;
+    pc = pc * r2 - 1.0 / 87178291200.0;
+    pc = pc * r2 + 1.0 / 479001600.0;
+    pc = pc * r2 - 1.0 / 3628800.0;
+    pc = pc * r2 + 1.0 / 40320.0;
+    pc = pc * r2 - 1.0 / 720.0;
+    pc = pc * r2 + 1.0 / 24.0;
+    pc = pc * r2 - 0.5;
+    const double cr = 1.0 + r2 * pc;
+    const long long k = (long long)kf;
+    double sv, cv;
+    switch ((int)(k & 3)) {
+        case 0: sv = sr; cv = cr; break;
+        case 1: sv = cr; cv = -sr; break;
+        case 2: sv = -sr; cv = -cr; break;
+        default: sv = -cr; cv = sr; break;
+    }
+    s = (float)sv;
+    c = (float)cv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side render loop.  One lane = one pixel; a wave = an 8x8 pixel block of a bucket, buckets are
+// dealt to ranks round-robin (bucket i -> rank i % world).  color_hit's recursion (render.hpp:133-308) is
+// run as a per-lane state machine around ONE wave-wide trace call per iteration; refractive forks and
+// diffuse-GI parents keep their partial results in a small per-lane frame stack, evaluated in the same
+// order as the recursion so the floating-point results are identical.
+
+enum : int { ST_NEW_SAMPLE = 0, ST_TRACE, ST_SHADE, ST_LIGHT, ST_RETURN, ST_DONE };
+enum : int { PEND_CHILD_BG = 0, PEND_CHILD_BLACK = 1, PEND_SHADOW = 2 };
+enum : uint32_t { FR_REFR_A = 0, FR_REFR_B = 1, FR_DIFFUSE = 2 };
+
+struct Frame {            // 14 dwords, lives in scratch; touched only at refractive / GI events
+    float a[12];
+    uint32_t meta;        // kind | depth << 8 | iteration << 16
+    uint32_t tri;
+};
+
+template <int MODE, bool STATS, bool FORKS, bool LDS_NODES>
+__global__ __launch_bounds__(256) void k_render(RenderArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
+    if (LDS_NODES) stage_nodes(A.tree.nodes, A.tree.n_nodes, lds_nodes);
+
+    // ---- pixel assignment (tile/bucket.hpp:7-21 buckets, 8x8 blocks inside, round-robin over ranks)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
+    const uint32_t local_bucket = gwave / bpb, sub = gwave % bpb;
+    const uint32_t bucket = (uint32_t)A.rank + local_bucket * (uint32_t)A.world;
+    bool valid = bucket < A.n_buckets;
+    const uint32_t bx = (bucket % A.tiles_x) * A.bucket, by = (bucket / A.tiles_x) * A.bucket;
+    const uint32_t lx = (sub % A.blocks_per_bucket_side) * 8u + (lane & 7u);
+    const uint32_t ly = (sub / A.blocks_per_bucket_side) * 8u + (lane >> 3);
+    const uint32_t px = bx + lx, py = by + ly;
+    valid = valid & (lx < A.bucket) & (ly < A.bucket) & (px < A.width) & (py < A.height);
+
+    const V3 background = mk(A.background[0], A.background[1], A.background[2]);
+    const V3 black = mk(0.f, 0.f, 0.f);
+    const float PI_F = 3.14159265358979323846f;
+    const uint32_t pixel = py * A.width + px;
+    const uint32_t seed_hash = pcg_hash(A.seed);
+
+    // ---- per-lane path state
+    int state = valid ? ST_NEW_SAMPLE : ST_DONE;
+    int pend = PEND_CHILD_BG;
+    int sample = 0, depth = 0, light_k = 0;
+    uint32_t draws = 0, nrays = 0;
+    bool cull = false;
+    Ray ray = make_ray(black, mk(1.f, 1.f, 1.f));
+    V3 pixel_sum = black, ret = black;
+    // hit being shaded / lit
+    V3 P = black, hn = black, fn = black, din = black, ncos = black, acc = black, albedo = black;
+    uint32_t hit_tri = 0, hit_mat = 0;
+    float shadow_max_t = 0.f, contrib = 0.f;
+    Frame frames[FORKS ? kMaxRayDepth : 1];
+    int fsp = 0;
+    Stats st = {0, 0, 0, 0, 0, 0};
+    Cand cand;
+    cand.t = kFltMax; cand.u = cand.v = 0.f; cand.k = kMiss;
+
+    for (;;) {
+        // ---------- resolve: run each lane forward until it needs a ray traced (or is done)
+        while (state != ST_TRACE && state != ST_DONE) {
+            if (state == ST_NEW_SAMPLE) {                                   // render.hpp:35-69
+                if (sample == A.spp) {
+                    const float inv = (float)A.spp;
+                    float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
+                    o[0] = pixel_sum.x / inv; o[1] = pixel_sum.y / inv; o[2] = pixel_sum.z / inv;   // render.hpp:72
+                    state = ST_DONE;
+                    continue;
+                }
+                draws = 0;
+                float rx = (float)px, ry = (float)py;
+                if (A.spp == 1) { rx += 0.5f; ry += 0.5f; }
+                else {
+                    rx += urand01(seed_hash, pixel, (uint32_t)sample, draws++);
+                    ry += urand01(seed_hash, pixel, (uint32_t)sample, draws++);
+                }
+                const float ndc_x = rx / (float)A.width, ndc_y = ry / (float)A.height;
+                float sx = (2.0f * ndc_x) - 1.0f;
+                float sy = 1.0f - (2.0f * ndc_y);
+                sx *= A.aspect;
+                sx = (float)((double)sx * A.tan_half_fov);                  // render.hpp:55-57 (float *= double)
+                sy = (float)((double)sy * A.tan_half_fov);
+                const float *M = A.cam_mat;                                 // transpose(camera.matrix) * dir
+                V3 d = mk(M[0] * sx + M[3] * sy + M[6] * -1.0f, M[1] * sx + M[4] * sy + M[7] * -1.0f,
+                          M[2] * sx + M[5] * sy + M[8] * -1.0f);
+                d = normalized(d);
+                ray = make_ray(mk(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]), d);
+                cull = true; depth = 0; pend = PEND_CHILD_BG; fsp = 0;
+                state = ST_TRACE;
+            } else if (state == ST_SHADE) {                                 // color_hit, render.hpp:133-308
+                if (depth == A.max_depth) { ret = background; state = ST_RETURN; continue; }   // :138-139
+                const DevMaterial *mat = A.materials + hit_mat;
+                const int kind = mat->kind;
+                if (kind == RTK_MAT_CONSTANT) {
+                    ret = mk(mat->albedo[0], mat->albedo[1], mat->albedo[2]);                  // :302-303
+                    state = ST_RETURN;
+                } else if (kind == RTK_MAT_REFLECTIVE) {                                        // :239-250
+                    const V3 rd = din - ((2.0f * dot(din, hn)) * hn);
+                    const V3 ro = P + (A.reflection_bias * rd);
+                    ray = make_ray(ro, rd);
+                    cull = false; depth += 1; pend = PEND_CHILD_BG;
+                    state = ST_TRACE;
+                } else if (kind == RTK_MAT_REFRACTIVE) {                                        // :252-301
+                    V3 n = normalized(mat->smooth ? hn : fn);
+                    const V3 i = normalized(din);
+                    float eta_i = 1.0f, eta_r = mat->ior;
+                    if (0.0f < dot(i, n)) { const float tmp = eta_i; eta_i = eta_r; eta_r = tmp; n = neg(n); }
+                    const float cos_i_n = -dot(i, n);
+                    const float sin_i_n = __builtin_sqrtf(1.0f - cos_i_n * cos_i_n);
+                    const V3 rd = i - ((2.0f * dot(i, n)) * n);
+                    const V3 ro = P + (A.reflection_bias * rd);
+                    if (eta_r / eta_i < sin_i_n) {                                              // total internal reflection
+                        ray = make_ray(ro, rd);
+                        cull = false; depth += 1; pend = PEND_CHILD_BLACK;
+                        state = ST_TRACE;
+                    } else {
+                        const float sin_r = ((sin_i_n * eta_i) / eta_r);
+                        const float cos_r = __builtin_sqrtf(1.0f - sin_r * sin_r);
+                        const V3 r = (cos_r * neg(n)) + (sin_r * normalized(i + (cos_i_n * n)));
+                        const double x = (double)(1.0f + dot(i, n));                           // :300, x^5 in double
+                        const float fresnel = (float)(0.5 * (x * x * x * x * x));
+                        if (FORKS) {
+                            Frame &f = frames[fsp++];
+                            f.a[0] = ro.x; f.a[1] = ro.y; f.a[2] = ro.z;
+                            f.a[3] = rd.x; f.a[4] = rd.y; f.a[5] = rd.z;
+                            f.a[6] = fresnel;
+                            f.meta = FR_REFR_A | ((uint32_t)depth << 8);
+                        }
+                        ray = make_ray(P + (A.refraction_bias * r), r);
+                        cull = false; depth += 1; pend = PEND_CHILD_BLACK;
+                        state = ST_TRACE;
+                    }
+                } else {                                                                        // diffuse, :148-209
+                    albedo = mk(mat->albedo[0], mat->albedo[1], mat->albedo[2]);
+                    ncos = mat->smooth ? hn : fn;
+                    acc = black;
+                    if (FORKS && A.diffuse_rays > 0) {
+                        Frame &f = frames[fsp++];
+                        f.a[0] = P.x; f.a[1] = P.y; f.a[2] = P.z;
+                        f.a[3] = din.x; f.a[4] = din.y; f.a[5] = din.z;
+                        f.a[6] = hn.x; f.a[7] = hn.y; f.a[8] = hn.z;
+                        f.a[9] = 0.f; f.a[10] = 0.f; f.a[11] = 0.f;
+                        f.meta = FR_DIFFUSE | ((uint32_t)depth << 8);
+                        f.tri = hit_tri;
+                        state = ST_RETURN;      // the frame handler below issues GI ray 0 (ret = 0 adds nothing)
+                        ret = black;
+                        f.meta |= 0xFFFF0000u;  // iteration = -1: "no child returned yet"
+                    } else {
+                        light_k = 0;
+                        state = ST_LIGHT;
+                    }
+                }
+            } else if (state == ST_LIGHT) {                                 // light loop, render.hpp:184-208
+                if (light_k == A.n_lights) {
+                    const float div = (float)(A.diffuse_rays + 1);
+                    ret = mk(acc.x / div, acc.y / div, acc.z / div);
+                    state = ST_RETURN;
+                    continue;
+                }
+                const DevLight *L = A.lights + light_k;
+                V3 ld = mk(L->pos[0], L->pos[1], L->pos[2]) - P;
+                const float radius = length(ld);
+                const float area = 4.0f * PI_F * radius * radius;
+                ld = normalized(ld);
+                const float d0 = dot(ld, ncos);
+                const float cosine = (0.0f < d0) ? d0 : 0.0f;                // std::max(0, dot)
+                contrib = (L->intensity / area) * cosine;
+                if (0.0f < radius) {                                         // is_occluded's loop guard, :114
+                    ray = make_ray(P + (A.shadow_bias * ld), ld);
+                    shadow_max_t = radius;
+                    cull = false; pend = PEND_SHADOW;
+                    state = ST_TRACE;
+                } else {
+                    acc = acc + (contrib * albedo);
+                    light_k += 1;
+                }
+            } else {                                                         // ST_RETURN: hand `ret` to the caller
+                if (!FORKS || fsp == 0) {
+                    pixel_sum = pixel_sum + ret;                             // render.hpp:66
+                    sample += 1;
+                    state = ST_NEW_SAMPLE;
+                    continue;
+                }
+                Frame &f = frames[fsp - 1];
+                const uint32_t kind = f.meta & 0xFFu;
+                const int fdepth = (int)((f.meta >> 8) & 0xFFu);
+                if (kind == FR_REFR_A) {                                     // refraction subtree done -> reflection ray
+                    f.a[7] = ret.x; f.a[8] = ret.y; f.a[9] = ret.z;
+                    f.meta = FR_REFR_B | ((uint32_t)fdepth << 8);
+                    ray = make_ray(mk(f.a[0], f.a[1], f.a[2]), mk(f.a[3], f.a[4], f.a[5]));
+                    cull = false; depth = fdepth + 1; pend = PEND_CHILD_BLACK;
+                    state = ST_TRACE;
+                } else if (kind == FR_REFR_B) {                              // :301
+                    const float fresnel = f.a[6];
+                    const V3 refr = mk(f.a[7], f.a[8], f.a[9]);
+                    ret = (fresnel * ret) + ((1.0f - fresnel) * refr);
+                    fsp -= 1;
+                } else {                                                     // FR_DIFFUSE: GI loop, :151-182
+                    int it = (int)(short)(f.meta >> 16);
+                    if (it >= 0) { f.a[9] += ret.x; f.a[10] += ret.y; f.a[11] += ret.z; }
+                    it += 1;
+                    const V3 fP = mk(f.a[0], f.a[1], f.a[2]);
+                    const V3 fhn = mk(f.a[6], f.a[7], f.a[8]);
+                    if (it < A.diffuse_rays) {
+                        f.meta = FR_DIFFUSE | ((uint32_t)fdepth << 8) | ((uint32_t)it << 16);
+                        const V3 fd = mk(f.a[3], f.a[4], f.a[5]);
+                        const V3 right = normalized(cross(fd, fhn));
+                        const V3 up = fhn;
+                        const V3 fwd = cross(right, up);
+                        const float a_xy = PI_F * urand01(seed_hash, pixel, (uint32_t)sample, draws++);
+                        float s1, c1;
+                        det_sincos(a_xy, s1, c1);
+                        V3 rv = mk(c1, s1, 0.0f);
+                        const float a_xz = PI_F * urand01(seed_hash, pixel, (uint32_t)sample, draws++) * 2.0f;
+                        float s2, c2;
+                        det_sincos(a_xz, s2, c2);
+                        rv = mk(c2 * rv.x + 0.0f * rv.y + (-s2) * rv.z, 0.0f * rv.x + 1.0f * rv.y + 0.0f * rv.z,
+                                s2 * rv.x + 0.0f * rv.y + c2 * rv.z);
+                        const V3 org = fP + (A.reflection_bias * fhn);
+                        const V3 dir = mk(right.x * rv.x + right.y * rv.y + right.z * rv.z,
+                                          up.x * rv.x + up.y * rv.y + up.z * rv.z,
+                                          fwd.x * rv.x + fwd.y * rv.y + fwd.z * rv.z);
+                        ray = make_ray(org, dir);
+                        cull = false; depth = fdepth + 1; pend = PEND_CHILD_BLACK;
+                        state = ST_TRACE;
+                    } else {                                                 // GI done: light this hit
+                        P = fP; hn = fhn;
+                        acc = mk(f.a[9], f.a[10], f.a[11]);
+                        hit_tri = f.tri;
+                        const DevShade *sh = A.tree.shade + hit_tri;
+                        fn = mk(sh->fn[0], sh->fn[1], sh->fn[2]);
+                        hit_mat = sh->material;
+                        const DevMaterial *mat = A.materials + hit_mat;
+                        albedo = mk(mat->albedo[0], mat->albedo[1], mat->albedo[2]);
+                        ncos = mat->smooth ? hn : fn;
+                        depth = fdepth;
+                        fsp -= 1;
+                        light_k = 0;
+                        state = ST_LIGHT;
+                    }
+                }
+            }
+        }
+
+        // ---------- one wave-wide closest-hit query for every lane that has a ray pending
+        const bool need = (state == ST_TRACE);
+        if (__ballot(need) == 0ull) break;
+        cand = trace<MODE, STATS, LDS_NODES>(A.tree, lds_nodes, ray, cull, need, st);
+
+        // ---------- consume
+        if (need) {
+            nrays += 1;
+            const bool hit = cand.k != kMiss;
+            if (pend == PEND_SHADOW) {                                       // is_occluded, render.hpp:110-131
+                bool clear = !hit | (shadow_max_t < cand.t);
+                bool again = false;
+                if (!clear && A.has_refractive) {
+                    const uint32_t tri = A.tree.tri_ids[cand.k];
+                    const uint32_t m = A.tree.shade[tri].material;
+                    if (A.materials[m].kind == RTK_MAT_REFRACTIVE) {         // transmissive: step through, :126-127
+                        const V3 hp = ray.o + (cand.t * ray.d);
+                        ray.o = hp + (A.shadow_bias * ray.d);
+                        shadow_max_t -= cand.t;
+                        if (0.0f < shadow_max_t) again = true; else clear = true;
+                    }
+                }
+                if (!again) {
+                    if (clear) acc = acc + (contrib * albedo);               // :205
+                    light_k += 1;
+                    state = ST_LIGHT;
+                }
+            } else if (!hit) {
+                ret = (pend == PEND_CHILD_BG) ? background : black;
+                state = ST_RETURN;
+            } else {
+                const Surface s = reconstruct(A.tree, cand);
+                P = ray.o + (cand.t * ray.d);                                // kd_tree_simd.hpp:254
+                hn = s.hit_normal; fn = s.face_normal; din = ray.d;
+                hit_tri = s.tri; hit_mat = s.material;
+                state = ST_SHADE;
+            }
+        }
+    }
+
+    const uint32_t total = wave_sum(nrays);
+    if (STATS) flush_stats(st, 0u, A.counters);
+    if (lane == 0u) atomicAdd(A.counters + 0, (unsigned long long)total);
+}
+
+// ------------------------------------------------------------------------------------------------
+// After the all-gather: [world][buckets_per_rank][bucket*bucket][3] -> frame [h][w][3].
+__global__ __launch_bounds__(256) void k_assemble(AssembleArgs A) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)A.width * A.height) return;
+    const uint32_t px = (uint32_t)(i % A.width), py = (uint32_t)(i / A.width);
+    const uint32_t bucket = (py / A.bucket) * A.tiles_x + (px / A.bucket);
+    const uint32_t rank = bucket % A.world, local = bucket / A.world;
+    const size_t src = (((size_t)rank * A.buckets_per_rank + local) * A.bucket + (py % A.bucket)) * A.bucket + (px % A.bucket);
+    A.rgb[i * 3 + 0] = A.gathered[src * 3 + 0];
+    A.rgb[i * 3 + 1] = A.gathered[src * 3 + 1];
+    A.rgb[i * 3 + 2] = A.gathered[src * 3 + 2];
+}
+
+}  // namespace dev
+
+// ------------------------------------------------------------------------------------------------ launchers
+
+namespace {
+
+template <int MODE, bool STATS>
+hipError_t launch_intersect_m(const dev::IntersectArgs &A, bool lds, size_t lds_bytes, hipStream_t s) {
+    const unsigned blocks = (unsigned)((A.n + 255) / 256);
+    if (blocks == 0) return hipSuccess;
+    if (lds) hipLaunchKernelGGL((dev::k_intersect<MODE, STATS, true>), dim3(blocks), dim3(256), lds_bytes, s, A);
+    else hipLaunchKernelGGL((dev::k_intersect<MODE, STATS, false>), dim3(blocks), dim3(256), 0, s, A);
+    return hipGetLastError();
+}
+
+template <int MODE, bool STATS, bool FORKS>
+hipError_t launch_render_m(const dev::RenderArgs &A, unsigned blocks, bool lds, size_t lds_bytes, hipStream_t s) {
+    if (lds) hipLaunchKernelGGL((dev::k_render<MODE, STATS, FORKS, true>), dim3(blocks), dim3(256), lds_bytes, s, A);
+    else hipLaunchKernelGGL((dev::k_render<MODE, STATS, FORKS, false>), dim3(blocks), dim3(256), 0, s, A);
+    return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launch_render_mode(const dev::RenderArgs &A, unsigned blocks, bool stats, bool forks, bool lds, size_t lds_bytes,
+                              hipStream_t s) {
+    if (stats) return forks ? launch_render_m<MODE, true, true>(A, blocks, lds, lds_bytes, s)
+                            : launch_render_m<MODE, true, false>(A, blocks, lds, lds_bytes, s);
+    return forks ? launch_render_m<MODE, false, true>(A, blocks, lds, lds_bytes, s)
+                 : launch_render_m<MODE, false, false>(A, blocks, lds, lds_bytes, s);
+}
+
+}  // namespace
+
+hipError_t launch_intersect(const dev::IntersectArgs &A, int mode, bool stats, hipStream_t s) {
+    const size_t lds_bytes = (size_t)A.tree.n_nodes * sizeof(DevNode);
+    const bool lds = lds_bytes <= kMaxNodeLdsBytes;
+    switch (mode) {
+        case RTK_TRACE_LANE:
+            return stats ? launch_intersect_m<RTK_TRACE_LANE, true>(A, lds, lds_bytes, s)
+                         : launch_intersect_m<RTK_TRACE_LANE, false>(A, lds, lds_bytes, s);
+        case RTK_TRACE_WAVE:
+            return stats ? launch_intersect_m<RTK_TRACE_WAVE, true>(A, lds, lds_bytes, s)
+                         : launch_intersect_m<RTK_TRACE_WAVE, false>(A, lds, lds_bytes, s);
+        default:
+            return stats ? launch_intersect_m<RTK_TRACE_AUTO, true>(A, lds, lds_bytes, s)
+                         : launch_intersect_m<RTK_TRACE_AUTO, false>(A, lds, lds_bytes, s);
+    }
+}
+
+hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool forks, hipStream_t s) {
+    const size_t lds_bytes = (size_t)A.tree.n_nodes * sizeof(DevNode);
+    const bool lds = lds_bytes <= kMaxNodeLdsBytes;
+    const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
+    const uint64_t waves = (uint64_t)A.buckets_per_rank * bpb;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (blocks == 0) return hipSuccess;
+    switch (mode) {
+        case RTK_TRACE_LANE: return launch_render_mode<RTK_TRACE_LANE>(A, blocks, stats, forks, lds, lds_bytes, s);
+        case RTK_TRACE_WAVE: return launch_render_mode<RTK_TRACE_WAVE>(A, blocks, stats, forks, lds, lds_bytes, s);
+        default: return launch_render_mode<RTK_TRACE_AUTO>(A, blocks, stats, forks, lds, lds_bytes, s);
+    }
+}
+
+hipError_t launch_assemble(const dev::AssembleArgs &A, hipStream_t s) {
+    const size_t n = (size_t)A.width * A.height;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(dev::k_assemble, dim3(blocks), dim3(256), 0, s, A);
+    return hipGetLastError();
+}
+
+}  // namespace rtk

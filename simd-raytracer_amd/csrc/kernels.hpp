@@ -1,0 +1,70 @@
+// Kernel argument blocks and launchers shared by kernels.hip and api.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rtk_internal.hpp"
+
+namespace rtk {
+
+constexpr int kMaxRayDepth = 16;                 // frame-stack capacity of the render kernel
+constexpr size_t kMaxNodeLdsBytes = 48 * 1024;   // node arrays up to this size are staged in LDS (1536 nodes)
+
+}  // namespace rtk
+
+#include "trace.hip.hpp"
+
+namespace rtk {
+namespace dev {
+
+struct IntersectArgs {
+    TreeView tree;
+    const rtk_ray *rays;
+    rtk_hit *out;
+    size_t n;
+    int cull;
+    unsigned long long *counters;
+};
+
+struct RenderArgs {
+    TreeView tree;
+    const DevMaterial *materials;
+    const DevLight *lights;
+    int n_lights;
+    int has_refractive;
+    float cam_pos[3];
+    float cam_mat[9];
+    float background[3];
+    uint32_t width, height;
+    float aspect;
+    double tan_half_fov;
+    int spp, max_depth, diffuse_rays;
+    uint32_t seed;
+    float shadow_bias, reflection_bias, refraction_bias;
+    // bucket sharding
+    uint32_t bucket, tiles_x, tiles_y, n_buckets, blocks_per_bucket_side;
+    uint32_t buckets_per_rank;
+    int rank, world;
+    int compact;                      // 1: out is [buckets_per_rank][bucket][bucket][3]; 0: out is [h][w][3]
+    float *out;
+    unsigned long long *counters;
+
+    __device__ __forceinline__ size_t out_index(uint32_t local_bucket, uint32_t lx, uint32_t ly, uint32_t px,
+                                                uint32_t py) const {
+        return compact ? (((size_t)local_bucket * bucket + ly) * bucket + lx) : ((size_t)py * width + px);
+    }
+};
+
+struct AssembleArgs {
+    const float *gathered;
+    float *rgb;
+    uint32_t width, height, bucket, tiles_x, world, buckets_per_rank;
+};
+
+}  // namespace dev
+
+hipError_t launch_intersect(const dev::IntersectArgs &A, int mode, bool stats, hipStream_t s);
+hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool forks, hipStream_t s);
+hipError_t launch_assemble(const dev::AssembleArgs &A, hipStream_t s);
+
+}  // namespace rtk

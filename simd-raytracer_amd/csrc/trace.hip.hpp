@@ -1,0 +1,288 @@
+// Device-side traversal and intersection for gfx950 (wave64).  Compile with -ffp-contract=off:
+// every expression keeps the reference's operation order so IEEE add/mul/div/sqrt reproduce the
+// CPU results bit for bit.  Reference paths are relative to
+// /root/reference/include/raytracer/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rtk_internal.hpp"
+
+namespace rtk {
+namespace dev {
+
+constexpr float kFltMax = 3.402823466e+38f;
+constexpr uint32_t kMiss = 0xFFFFFFFFu;
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }   // vec3.hpp:77-79
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }   // vec3.hpp:81-83
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }      // vec3.hpp:94-97
+__device__ __forceinline__ V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }  // vec3.hpp:119-122
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {                                                     // vec3.hpp:124-131
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float length(V3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); } // vec3.hpp:85-91
+__device__ __forceinline__ V3 normalized(V3 a) {                                                      // vec3.hpp:104-108
+    const float inv_length = (1.0f / length(a));
+    return V3{a.x * inv_length, a.y * inv_length, a.z * inv_length};
+}
+
+struct Ray {            // ray3<F>, ray3.hpp:5-15
+    V3 o, d, inv;
+};
+__device__ __forceinline__ Ray make_ray(V3 o, V3 d) {
+    Ray r;
+    r.o = o; r.d = d;
+    r.inv = V3{(1.0f / d.x), (1.0f / d.y), (1.0f / d.z)};                     // vec3.hpp:99-102
+    return r;
+}
+
+struct Cand {           // kd_tree_simd.hpp:86-93 hit_candidate, with the leaf-ref index instead of (pack, lane)
+    float t, u, v;
+    uint32_t k;         // index into the leaf-ref arrays; kMiss = no hit
+};
+
+struct Stats {          // per-lane work counters (only in STATS kernels)
+    uint32_t nodes, boxpass, leaves, tris, packets16, hits;
+};
+
+struct TreeView {
+    const DevNode *nodes;
+    const DevTri *tris;
+    const uint32_t *tri_ids;
+    const DevShade *shade;
+    uint32_t n_nodes;
+    float eps;
+    int normalize;
+};
+
+// Wave-uniform loads: address space 4 (constant) forces s_load_* through the scalar cache, so one
+// fetch of a node / triangle serves all 64 rays of the wave.
+typedef const uint32_t __attribute__((address_space(4))) *cptr_u32;
+typedef const float __attribute__((address_space(4))) *cptr_f32;
+
+// aabb3::intersect(ray), aabb3.hpp:74-90.  Explicit compare+select in the reference's order so that
+// NaNs (0*inf when a direction component is 0) take the same path as std::minmax/max/min; the
+// per-axis early return is an OR of the three "t_max < t_min" tests (once true it stays a miss).
+__device__ __forceinline__ bool slab(const float lo0, const float lo1, const float lo2, const float hi0, const float hi1,
+                                     const float hi2, const Ray &r, float &t_min_out) {
+    float t_min = 0.0f, t_max = kFltMax;
+    bool miss;
+    {
+        const float a = (lo0 - r.o.x) * r.inv.x, c = (hi0 - r.o.x) * r.inv.x;
+        const float t1 = (c < a) ? c : a, t2 = (c < a) ? a : c;
+        t_min = (t_min < t1) ? t1 : t_min;
+        t_max = (t2 < t_max) ? t2 : t_max;
+        miss = t_max < t_min;
+    }
+    {
+        const float a = (lo1 - r.o.y) * r.inv.y, c = (hi1 - r.o.y) * r.inv.y;
+        const float t1 = (c < a) ? c : a, t2 = (c < a) ? a : c;
+        t_min = (t_min < t1) ? t1 : t_min;
+        t_max = (t2 < t_max) ? t2 : t_max;
+        miss = miss | (t_max < t_min);
+    }
+    {
+        const float a = (lo2 - r.o.z) * r.inv.z, c = (hi2 - r.o.z) * r.inv.z;
+        const float t1 = (c < a) ? c : a, t2 = (c < a) ? a : c;
+        t_min = (t_min < t1) ? t1 : t_min;
+        t_max = (t2 < t_max) ? t2 : t_max;
+        miss = miss | (t_max < t_min);
+    }
+    t_min_out = t_min;
+    return !miss;
+}
+
+// One lane of triangle_packet::intersect<cull,eps> (kd_tree_simd.hpp:25-60) followed by the winner rule of
+// intersect_leaf (:266-302) and intersect (:222-226): within a leaf the earliest triangle with the
+// smallest t wins, across leaves only a strictly smaller t replaces — i.e. a running strict '<'.
+__device__ __forceinline__ void test_triangle(const float v0x, const float v0y, const float v0z, const float e1x,
+                                              const float e1y, const float e1z, const float e2x, const float e2y,
+                                              const float e2z, const Ray &r, const bool cull, const float eps,
+                                              const uint32_t k, const bool enabled, Cand &best) {
+    const float pvx = r.d.y * e2z - r.d.z * e2y;
+    const float pvy = r.d.z * e2x - r.d.x * e2z;
+    const float pvz = r.d.x * e2y - r.d.y * e2x;
+    const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+    bool m = enabled & (eps <= (cull ? det : __builtin_fabsf(det)));
+    const float inv_det = (1.0f / det);
+    const float tvx = r.o.x - v0x, tvy = r.o.y - v0y, tvz = r.o.z - v0z;
+    const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv_det;
+    m = m & (0.0f <= u) & (u <= 1.0f);
+    const float qx = tvy * e1z - tvz * e1y;
+    const float qy = tvz * e1x - tvx * e1z;
+    const float qz = tvx * e1y - tvy * e1x;
+    const float v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv_det;
+    m = m & (0.0f <= v) & (u + v <= 1.0f);
+    const float t = (e2x * qx + e2y * qy + e2z * qz) * inv_det;
+    m = m & (eps < t) & (t < best.t);
+    if (m) { best.t = t; best.u = u; best.v = v; best.k = k; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-lane traversal: every lane walks the tree on its own.  The traversal order of the reference is
+// ray-independent (child1 then child0, no near/far sort), so the LIFO stack of kd_tree_simd.hpp:191-214
+// collapses to one index into the traversal-ordered node array: pass+inner -> n+1, otherwise -> skip.
+// `n` and `best` are the complete traversal state, which is what lets the wave path hand over mid-tree.
+template <bool STATS, bool LDS_NODES>
+__device__ __forceinline__ void trace_lane_from(const TreeView &T, const DevNode *lds_nodes, const Ray &r, const bool cull,
+                                                uint32_t n, Cand &best, Stats &st) {
+    const uint32_t end = T.n_nodes;
+    for (;;) {
+        uint32_t leaf_first = 0, leaf_count = 0;
+        while (n < end) {
+            const DevNode *np = LDS_NODES ? (lds_nodes + n) : (T.nodes + n);
+            const float4 q0 = *reinterpret_cast<const float4 *>(np);
+            const float4 q1 = *(reinterpret_cast<const float4 *>(np) + 1);
+            const uint32_t a = __float_as_uint(q1.z), b = __float_as_uint(q1.w);
+            float t_min;
+            const bool box = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, t_min);
+            const bool pass = box & !(best.t < t_min);                     // kd_tree_simd.hpp:202-205
+            if (STATS) { st.nodes += 1; st.boxpass += pass ? 1u : 0u; }
+            const bool inner = (b == DEV_INNER);
+            if (pass & !inner) { leaf_first = a; leaf_count = b; n += 1; break; }
+            n = (pass | !inner) ? n + 1 : a;
+        }
+        if (leaf_count == 0) break;
+        if (STATS) { st.leaves += 1; st.tris += leaf_count; st.packets16 += (leaf_count + 15u) >> 4; }
+        const float *tp = reinterpret_cast<const float *>(T.tris + leaf_first);
+        for (uint32_t k = 0; k < leaf_count; ++k, tp += 9) {
+            test_triangle(tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], tp[8], r, cull, T.eps, leaf_first + k,
+                          true, best);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-cooperative traversal: the wave walks the traversal-ordered node array ONCE for its 64 rays.
+// `n` is wave-uniform; each lane keeps `next`, the node it wants to visit next (>= n always).  A lane
+// takes part in node n iff next == n.  Because skip targets nest, "some lane descends ? n+1 : skip" never
+// jumps past a node another lane is waiting for.  Nodes and triangles are fetched with scalar loads.
+// Lanes see exactly the node/triangle sequence they would see alone, so results are identical.
+// Returns the lanes' `next` so the caller can continue per-lane (hand-over) if it left early.
+template <bool STATS>
+__device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, const bool cull, const bool active,
+                                               Cand &best, Stats &st, const uint32_t min_lanes) {
+    const uint32_t end = T.n_nodes;
+    uint32_t next = active ? 0u : end;
+    uint32_t n = 0;
+    cptr_u32 nodes = (cptr_u32)(const void *)T.nodes;
+    cptr_f32 tris = (cptr_f32)(const void *)T.tris;
+    while (n < end) {
+        cptr_u32 np = nodes + (size_t)n * 8;
+        const float lo0 = __uint_as_float(np[0]), lo1 = __uint_as_float(np[1]), lo2 = __uint_as_float(np[2]);
+        const float hi0 = __uint_as_float(np[3]), hi1 = __uint_as_float(np[4]), hi2 = __uint_as_float(np[5]);
+        const uint32_t a = np[6], b = np[7];
+        const bool part = (next == n);
+        const unsigned long long part_mask = __ballot(part);
+        if (part_mask == 0ull) {                                           // nobody is waiting here
+            n = (b == DEV_INNER) ? a : n + 1;
+            continue;
+        }
+        if ((uint32_t)__popcll(part_mask) < min_lanes) break;              // too few rays agree: hand over to per-lane
+        float t_min;
+        const bool box = slab(lo0, lo1, lo2, hi0, hi1, hi2, r, t_min);
+        const bool pass = part & box & !(best.t < t_min);
+        if (STATS) { st.nodes += part ? 1u : 0u; st.boxpass += pass ? 1u : 0u; }
+        const bool any_pass = __ballot(pass) != 0ull;
+        if (b == DEV_INNER) {
+            if (part) next = pass ? n + 1 : a;
+            n = any_pass ? n + 1 : a;
+        } else {
+            if (part) next = n + 1;
+            if (any_pass) {
+                if (STATS && pass) { st.leaves += 1; st.tris += b; st.packets16 += (b + 15u) >> 4; }
+                cptr_f32 tp = tris + (size_t)a * 9;
+                for (uint32_t k = 0; k < b; ++k, tp += 9) {
+                    const float e2x = tp[6], e2y = tp[7], e2z = tp[8];
+                    const float e1x = tp[3], e1y = tp[4], e1z = tp[5];
+                    // same arithmetic as test_triangle, with wave-level early outs between the stages
+                    const float pvx = r.d.y * e2z - r.d.z * e2y;
+                    const float pvy = r.d.z * e2x - r.d.x * e2z;
+                    const float pvz = r.d.x * e2y - r.d.y * e2x;
+                    const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+                    bool m = pass & (T.eps <= (cull ? det : __builtin_fabsf(det)));
+                    if (__ballot(m) == 0ull) continue;
+                    const float inv_det = (1.0f / det);
+                    const float tvx = r.o.x - tp[0], tvy = r.o.y - tp[1], tvz = r.o.z - tp[2];
+                    const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv_det;
+                    m = m & (0.0f <= u) & (u <= 1.0f);
+                    if (__ballot(m) == 0ull) continue;
+                    const float qx = tvy * e1z - tvz * e1y;
+                    const float qy = tvz * e1x - tvx * e1z;
+                    const float qz = tvx * e1y - tvy * e1x;
+                    const float v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv_det;
+                    m = m & (0.0f <= v) & (u + v <= 1.0f);
+                    if (__ballot(m) == 0ull) continue;
+                    const float t = (e2x * qx + e2y * qy + e2z * qz) * inv_det;
+                    m = m & (T.eps < t) & (t < best.t);
+                    if (m) { best.t = t; best.u = u; best.v = v; best.k = a + k; }
+                }
+            }
+            n = n + 1;
+        }
+    }
+    return next;
+}
+
+// Closest hit for the wave's rays.  MODE: RTK_TRACE_LANE, RTK_TRACE_WAVE or RTK_TRACE_AUTO
+// (wave-cooperative while at least `kAutoMinLanes` rays share the node, then per-lane from where each ray stands).
+constexpr uint32_t kAutoMinLanes = 12;
+
+template <int MODE, bool STATS, bool LDS_NODES>
+__device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_nodes, const Ray &r, const bool cull,
+                                      const bool active, Stats &st) {
+    Cand best;
+    best.t = kFltMax; best.u = 0.0f; best.v = 0.0f; best.k = kMiss;
+    if (MODE == RTK_TRACE_LANE) {
+        trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, active ? 0u : T.n_nodes, best, st);
+    } else if (MODE == RTK_TRACE_WAVE) {
+        if (__ballot(active) != 0ull) (void)trace_wave<STATS>(T, r, cull, active, best, st, 1u);
+    } else {
+        const unsigned long long am = __ballot(active);
+        if (am != 0ull) {
+            uint32_t next = active ? 0u : T.n_nodes;
+            if ((uint32_t)__popcll(am) >= kAutoMinLanes) next = trace_wave<STATS>(T, r, cull, active, best, st, kAutoMinLanes);
+            trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, next, best, st);
+        }
+    }
+    if (STATS && best.k != kMiss) st.hits += 1;
+    return best;
+}
+
+// Hit reconstruction, kd_tree_simd.hpp:234-263.
+struct Surface {
+    V3 hit_normal, face_normal;
+    uint32_t tri, mesh, material;
+    float w;
+};
+__device__ __forceinline__ Surface reconstruct(const TreeView &T, const Cand &c) {
+    Surface s;
+    s.tri = T.tri_ids[c.k];
+    const DevShade *sh = T.shade + s.tri;
+    const float4 a = *reinterpret_cast<const float4 *>(sh);
+    const float4 b = *(reinterpret_cast<const float4 *>(sh) + 1);
+    const float4 cc = *(reinterpret_cast<const float4 *>(sh) + 2);
+    const float4 d = *(reinterpret_cast<const float4 *>(sh) + 3);
+    const V3 n0 = mk(a.x, a.y, a.z), n1 = mk(a.w, b.x, b.y), n2 = mk(b.z, b.w, cc.x);
+    s.face_normal = mk(cc.y, cc.z, cc.w);
+    s.mesh = __float_as_uint(d.x);
+    s.material = __float_as_uint(d.y);
+    s.w = 1.0f - c.u - c.v;
+    V3 hn = (c.u * n1 + c.v * n2) + s.w * n0;
+    if (T.normalize) hn = normalized(hn);                                  // kd_tree_simd.hpp:250 vs kd_tree.hpp:140
+    s.hit_normal = hn;
+    return s;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+}  // namespace dev
+}  // namespace rtk

@@ -1,0 +1,253 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same inputs.
+
+Bar: bit-exact for indices and — because both sides run the same IEEE operations in the same order with
+fp-contract off — also for every float (t, u, v, normals, pixels).  The stated tolerance of the north star is
+per-channel |delta| < 1e-4; the tests assert that and report when the result is not exactly 0.
+"""
+import numpy as np
+import pytest
+
+from conftest import CONFIG_SCENES, SCENE2, SCENE5, SCENE8
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+MODES = {"auto": 0, "lane": 1, "wave": 2}
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _scene_pair(rtk, ora, path, normalize=True, okind=None):
+    acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(path), normalize_hit_normal=normalize)
+    osc = ora.Scene(ora.load_crtscene(path))
+    oacc = ora.Accel(osc, ora.ACCEL_KD_SIMD if okind is None else okind)
+    return acc, oacc
+
+
+def _mixed_rays(flat, n, seed):
+    """Camera-like rays, random rays inside the scene box, axis-parallel rays (0 components -> inf/NaN slabs)."""
+    rng = np.random.default_rng(seed)
+    lo = flat.vertices.min(axis=0) - 1.0
+    hi = flat.vertices.max(axis=0) + 1.0
+    k = n // 4
+    # 1) from the camera towards points in the scene box
+    tgt = rng.uniform(lo, hi, size=(k, 3)).astype(np.float32)
+    o1 = np.broadcast_to(flat.cam_pos, (k, 3)).astype(np.float32)
+    d1 = tgt - o1
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True).astype(np.float32)
+    # 2) random origins in the box, random directions (un-normalised on purpose)
+    o2 = rng.uniform(lo, hi, size=(k, 3)).astype(np.float32)
+    d2 = rng.normal(size=(k, 3)).astype(np.float32)
+    # 3) axis-parallel and plane-parallel directions
+    o3 = rng.uniform(lo, hi, size=(k, 3)).astype(np.float32)
+    d3 = rng.normal(size=(k, 3)).astype(np.float32)
+    zero = rng.integers(0, 3, size=k)
+    d3[np.arange(k), zero] = 0.0
+    half = k // 2
+    d3[np.arange(half), (zero[:half] + 1) % 3] = 0.0
+    d3[np.arange(0, k, 7), zero[::7]] = -0.0
+    # 4) origins exactly on vertices / box planes, pointing at other vertices (edge and vertex grazing)
+    vi = rng.integers(0, flat.vertices.shape[0], size=(n - 3 * k, 2))
+    o4 = flat.vertices[vi[:, 0]].copy()
+    d4 = flat.vertices[vi[:, 1]] - o4 + np.float32(1e-3) * rng.normal(size=o4.shape).astype(np.float32)
+    o4 = o4 - d4  # start one segment length before the first vertex
+    rays = np.concatenate([np.concatenate([o, d], axis=1) for o, d in ((o1, d1), (o2, d2), (o3, d3), (o4, d4))])
+    return np.ascontiguousarray(rays.astype(np.float32))
+
+
+@pytest.mark.parametrize("scene", list(CONFIG_SCENES))
+@pytest.mark.parametrize("cull", [True, False])
+@pytest.mark.parametrize("mode", list(MODES))
+def test_intersect_matches_oracle(rtk, ora, scene, cull, mode):
+    acc, oacc = _scene_pair(rtk, ora, CONFIG_SCENES[scene])
+    rays = _mixed_rays(oacc.scene.flat, 60_000, seed=hash((scene, cull)) & 0xFFFF)
+    got = acc.intersect(rays, cull, MODES[mode])
+    ref = oacc.intersect(rays, cull)
+    assert np.array_equal(got["tri"], ref["tri"])
+    assert np.array_equal(got["mesh"], ref["mesh"])
+    for f in ("t", "u", "v"):
+        assert np.array_equal(_bits(got[f]), _bits(ref[f])), f
+    hit = ref["tri"] != 0xFFFFFFFF
+    assert hit.sum() > 1000
+    # hit_normal may be NaN for degenerate vertex normals on both sides; compare bit patterns of finite ones and NaN-ness
+    gn, rn = got["normal"][hit], ref["normal"][hit]
+    assert np.array_equal(np.isnan(gn), np.isnan(rn))
+    assert np.array_equal(_bits(np.nan_to_num(gn)), _bits(np.nan_to_num(rn)))
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 257, 1000])
+def test_intersect_ragged_sizes(rtk, ora, n):
+    acc, oacc = _scene_pair(rtk, ora, SCENE5)
+    rays = _mixed_rays(oacc.scene.flat, max(n, 8), seed=n)[:n]
+    for mode in MODES.values():
+        got = acc.intersect(rays, True, mode)
+        ref = oacc.intersect(rays, True)
+        assert got.shape == (n,)
+        assert np.array_equal(got["tri"], ref["tri"])
+        assert np.array_equal(_bits(got["t"]), _bits(ref["t"]))
+
+
+def test_intersect_unnormalized_normal_matches_kd_tree_accel(rtk, ora):
+    """normalize_hit_normal=0 reproduces kd_tree.hpp:140: compare with the scalar accel's normals."""
+    acc, oacc = _scene_pair(rtk, ora, SCENE5, normalize=False, okind=ora.ACCEL_KD_SCALAR)
+    rays = _mixed_rays(oacc.scene.flat, 40_000, seed=7)
+    got = acc.intersect(rays, False)
+    ref = oacc.intersect(rays, False)
+    assert np.array_equal(got["tri"], ref["tri"])
+    hit = ref["tri"] != 0xFFFFFFFF
+    assert np.array_equal(_bits(np.nan_to_num(got["normal"][hit])), _bits(np.nan_to_num(ref["normal"][hit])))
+
+
+RENDER_CASES = [
+    # name, scene, w, h, spp, depth, diffuse
+    ("scene5_640x480", SCENE5, 640, 480, 1, 5, 0),            # BASELINE config 1 shape
+    ("scene5_ragged_203x117", SCENE5, 203, 117, 1, 5, 0),     # not a multiple of 8 or of the bucket
+    ("scene8_480x270_d10", SCENE8, 480, 270, 1, 10, 0),       # refractive forks, config 3 at spp 1
+    ("hw15_scene2_384", SCENE2, 384, 384, 1, 5, 0),           # bucket 24
+    ("scene5_spp4", SCENE5, 320, 180, 4, 5, 0),               # jittered samples (counter-based RNG)
+    ("scene8_spp2_d10", SCENE8, 240, 136, 2, 10, 0),
+    ("hw15_scene2_gi", SCENE2, 160, 160, 8, 5, 1),            # config 4 shape: GI + refraction + reflection
+    ("hw15_scene2_gi3", SCENE2, 96, 96, 2, 4, 3),             # several diffuse rays per hit
+    ("scene5_depth0", SCENE5, 160, 90, 1, 0, 0),              # max_ray_depth 0 -> background everywhere hit
+    ("scene8_depth1", SCENE8, 160, 90, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", RENDER_CASES, ids=[c[0] for c in RENDER_CASES])
+@pytest.mark.parametrize("mode", list(MODES))
+def test_render_gate_a(rtk, ora, case, mode):
+    """Gate A: HIP frame vs the kd_tree_simd_accel restatement — expect max|delta| = 0, require < 1e-4."""
+    _, path, w, h, spp, depth, diffuse = case
+    acc, oacc = _scene_pair(rtk, ora, path)
+    cfg = rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=depth, diffuse_rays=diffuse, trace_mode=MODES[mode])
+    rgb, cn = acc.render_frame(cfg)
+    ref, ocn = oacc.render(w, h, spp, depth, diffuse)
+    assert cn["rays"] == ocn["rays"]
+    assert cn["primary"] == ocn["primary"] == w * h * spp
+    delta = float(np.max(np.abs(rgb - ref)))
+    assert delta < TOL
+    assert delta == 0.0, f"within tolerance but not bit-exact: {delta}"
+
+
+@pytest.mark.parametrize("scene", list(CONFIG_SCENES))
+def test_render_gate_b_kd_tree_accel(rtk, ora, scene):
+    """Gate B (BASELINE wording): normalize_hit_normal=0 vs the CPU kd_tree_accel render, |delta| < 1e-4."""
+    acc, oacc = _scene_pair(rtk, ora, CONFIG_SCENES[scene], normalize=False, okind=ora.ACCEL_KD_SCALAR)
+    depth = 10 if scene == "scene8" else 5
+    rgb, cn = acc.render_frame(rtk.RenderConfig(width=480, height=272, max_ray_depth=depth))
+    ref, ocn = oacc.render(480, 272, 1, depth, 0)
+    assert cn["rays"] == ocn["rays"]
+    assert float(np.max(np.abs(rgb - ref))) < TOL
+
+
+def test_render_config2_full_size(rtk, ora):
+    """BASELINE config 2 at full size: exact frame, and the ray count the reference itself produces."""
+    acc, oacc = _scene_pair(rtk, ora, SCENE5)
+    rgb, cn = acc.render_frame(rtk.RenderConfig(width=1920, height=1080, spp=1, max_ray_depth=5))
+    ref, ocn = oacc.render(1920, 1080, 1, 5, 0)
+    assert cn["rays"] == ocn["rays"] == 2_726_485
+    assert cn["primary"] == 2_073_600
+    assert float(np.max(np.abs(rgb - ref))) == 0.0
+    assert rtk.format_ppm(rgb) == ora.write_ppm(ref)
+
+
+@pytest.mark.parametrize("scene,depth", [("scene5", 5), ("scene8", 10), ("hw15_scene2", 5)])
+def test_work_counters_match_oracle(rtk, ora, scene, depth):
+    """Per-ray work (nodes popped, boxes passed, leaves, triangles, W=16 packets) equals the CPU restatement's:
+    the algorithmic-byte figure of the roofline is computed from these."""
+    acc, oacc = _scene_pair(rtk, ora, CONFIG_SCENES[scene])
+    for mode in MODES.values():
+        cfg = rtk.RenderConfig(width=320, height=184, max_ray_depth=depth, trace_mode=mode, collect_stats=True)
+        _, cn = acc.render_frame(cfg)
+        _, ocn = ora.Accel(oacc.scene, ora.ACCEL_KD_SIMD, W=16).render(320, 184, 1, depth, 0)
+        assert cn["rays"] == ocn["rays"]
+        assert cn["hits"] == ocn["hits"]
+        assert cn["nodes"] == ocn["nodes"]
+        assert cn["boxpass"] == ocn["boxpass"]
+        assert cn["leaves"] == ocn["leaves"]
+        assert cn["tris"] == ocn["tris"]
+        assert cn["packets16"] == ocn["packets"]
+
+
+# ---------------------------------------------------------------- size-independent properties at full size
+
+def test_full_size_properties_4k(rtk, ora):
+    """3840x2160 (config 5 resolution): run-to-run determinism, traversal-strategy independence and shard
+    independence, plus the oracle's ray count — properties that do not need a full-size reference image."""
+    import torch
+
+    acc, oacc = _scene_pair(rtk, ora, SCENE5)
+    w, h = 3840, 2160
+    base, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h))
+    again, _ = acc.render_frame(rtk.RenderConfig(width=w, height=h))
+    assert np.array_equal(_bits(base), _bits(again))
+    for mode in (1, 2):
+        other, cn2 = acc.render_frame(rtk.RenderConfig(width=w, height=h, trace_mode=mode))
+        assert cn2["rays"] == cn["rays"]
+        assert np.array_equal(_bits(base), _bits(other))
+    _, ocn = oacc.render(w, h, 1, 5, 0)
+    assert cn["rays"] == ocn["rays"]
+    # sharded over 3 ranks on one device, gathered and assembled
+    world = 3
+    cfgs = [rtk.RenderConfig(width=w, height=h, rank=r, world_size=world) for r in range(world)]
+    n = acc.output_floats(cfgs[0])
+    gathered = torch.empty((world, n), dtype=torch.float32, device="cuda")
+    for r in range(world):
+        acc.render_frame_device(cfgs[r], gathered[r].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+    acc.assemble_device(cfgs[0], gathered.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(base))
+
+
+@pytest.mark.parametrize("scene,w,h,world", [("scene5", 640, 360, 2), ("hw15_scene2", 200, 200, 4), ("scene8", 333, 77, 8)])
+def test_sharded_frames_assemble_to_the_unsharded_frame(rtk, ora, scene, w, h, world):
+    import torch
+
+    acc, _ = _scene_pair(rtk, ora, CONFIG_SCENES[scene])
+    depth = 10 if scene == "scene8" else 5
+    base, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h, max_ray_depth=depth))
+    cfgs = [rtk.RenderConfig(width=w, height=h, max_ray_depth=depth, rank=r, world_size=world) for r in range(world)]
+    n = acc.output_floats(cfgs[0])
+    gathered = torch.full((world, n), float("nan"), dtype=torch.float32, device="cuda")
+    rays = 0
+    stream = torch.cuda.current_stream().cuda_stream
+    for r in range(world):
+        acc.render_frame_device(cfgs[r], gathered[r].data_ptr(), stream)
+        rays += acc.last_counters()["rays"]
+    assert rays == cn["rays"]
+    out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+    acc.assemble_device(cfgs[0], gathered.data_ptr(), out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(base))
+
+
+def test_device_buffers_and_stream(rtk, ora):
+    """The device-pointer entry points on a non-default torch stream."""
+    import torch
+
+    acc, oacc = _scene_pair(rtk, ora, SCENE5)
+    rays = _mixed_rays(oacc.scene.flat, 10_000, seed=3)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d_rays = torch.from_numpy(rays).to("cuda", non_blocking=False)
+        d_hits = torch.empty((rays.shape[0], 32), dtype=torch.uint8, device="cuda")
+        acc.intersect_device(d_rays.data_ptr(), rays.shape[0], False, d_hits.data_ptr(), 0, s.cuda_stream)
+    s.synchronize()
+    got = d_hits.cpu().numpy().view(rtk.HIT_DTYPE).reshape(-1)
+    ref = oacc.intersect(rays, False)
+    assert np.array_equal(got["tri"], ref["tri"])
+    assert np.array_equal(_bits(got["t"]), _bits(ref["t"]))
+
+
+def test_bad_arguments_are_reported_not_thrown(rtk):
+    acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(SCENE5))
+    with pytest.raises(rtk.RtkError) as e:
+        acc.render_frame(rtk.RenderConfig(max_ray_depth=99))
+    assert e.value.code == rtk.RTK_ERR_INVALID
+    with pytest.raises(rtk.RtkError):
+        acc.render_frame(rtk.RenderConfig(spp=0))
+    with pytest.raises(rtk.RtkError):
+        acc.intersect(np.zeros((4, 6), np.float32), True, trace_mode=17)
