@@ -50,6 +50,15 @@ if not os.path.exists(_LIB_PATH):
         "(hipcc --offload-arch=gfx950).  This package has no CPU fallback."
     )
 
+# One HIP runtime per process: PyTorch bundles its own libamdhip64/libhsa-runtime64 (same sonames as the system
+# ROCm ones but different files).  If librtk_hip.so pulled in the system copies and torch its bundled ones, the
+# second runtime to initialise finds no device.  Importing torch first makes the loader satisfy librtk_hip.so's
+# libamdhip64.so.7 / libhsa-runtime64.so.1 from the copies torch already mapped.  Pure C/C++ hosts use system ROCm.
+try:
+    import torch  # noqa: F401  (plumbing only: device buffers, streams, torch.distributed)
+except ImportError:  # pragma: no cover - torch is part of the image
+    torch = None
+
 _L = C.CDLL(_LIB_PATH)
 
 
