@@ -70,9 +70,12 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Counter-based RNG (replaces utils/rand.hpp:5-19, see oracle/rt_oracle.c for the rationale) and the
-// deterministic double-precision sin/cos used for GI directions.  Same integer / IEEE-double operations
-// as the CPU side, so both produce identical bits.
+// Counter-based RNG: the reference's thread_local minstd_rand (utils/rand.hpp:5-19) is seeded identically on
+// every thread and handed out by a racy tile queue, so its stream cannot be reproduced.  Here a
+// draw is a pure function of (seed, absolute pixel, sample, draw index): frames do not depend on the wave/bucket/
+// rank layout.  det_sincos is a fixed double-precision sin/cos (Cody-Waite + Taylor) standing in for
+// std::sin/std::cos(float) at render.hpp:160-167: integer and IEEE-double operations only, so a CPU
+// restatement of the same formula reproduces it bit for bit.
 __device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
     const uint32_t s = x * 747796405u + 2891336453u;
     const uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;

@@ -1,0 +1,64 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo groups run the product's bucket layout + all-gather + assembly.
+The rank-local buffers are cut from an oracle frame (no GPU here); the GPU box runs the same code with RCCL."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, SCENE2, SCENE5
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, frame_np, bucket, result_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        par = importlib.import_module("simd-raytracer_amd.parallel")
+        frame = torch.from_numpy(frame_np)
+        h, w, _ = frame.shape
+        layout = par.BucketLayout(w, h, bucket, world)
+        local = par.extract_rank_buckets(frame, layout, rank)
+        assert local.numel() == layout.floats_per_rank
+        out = par.gather_frame(local, layout)
+        ok = torch.equal(out.view(torch.int32), frame.view(torch.int32))
+        np.save(os.path.join(result_dir, f"ok_{rank}.npy"), np.array([ok, local.numel()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scene,w,h,world", [(SCENE5, 203, 117, 2), (SCENE2, 100, 100, 3)])
+def test_sharded_gather_reassembles_the_frame(ora, tmp_path, scene, w, h, world):
+    flat = ora.load_crtscene(scene)
+    frame, _ = ora.Accel(ora.Scene(flat), ora.ACCEL_KD_SIMD).render(w, h, 1, 5, 0, n_threads=2)
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, frame, flat.bucket_size, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, n = np.load(tmp_path / f"ok_{r}.npy")
+        assert ok == 1, f"rank {r} assembled a different frame"
+
+
+def test_layout_matches_the_c_abi(rtk):
+    """BucketLayout (host python) and rtk_render_output_floats (C-ABI) agree on the rank-local buffer size."""
+    par = importlib.import_module("simd-raytracer_amd.parallel")
+    acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(SCENE2))
+    for (w, h, world) in [(1920, 1920, 8), (100, 37, 3), (24, 24, 2), (3840, 2160, 8)]:
+        lay = par.BucketLayout(w, h, acc.scene.info.bucket_size, world)
+        for r in range(world):
+            n = acc.output_floats(rtk.RenderConfig(width=w, height=h, rank=r, world_size=world))
+            assert n == lay.floats_per_rank
+        covered = sorted(b for r in range(world) for b in lay.buckets_of(r))
+        assert covered == list(range(lay.n_buckets))
+    assert acc.output_floats(rtk.RenderConfig(width=50, height=20)) == 50 * 20 * 3

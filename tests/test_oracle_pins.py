@@ -1,0 +1,148 @@
+"""Pins the CPU oracle to facts MEASURED ON THE REFERENCE ITSELF and recorded in SURVEY.md (§0.4, §6, §8).
+
+The reference ships no tests or golden vectors and cannot be built in this image without stand-in headers,
+so these reference-measured counters are the only pin available ("parity unpinned" at the per-pixel level
+against a reference binary — see oracle/rt_oracle.h).  They are strong: the per-frame intersect-call count
+depends on every shading-relevant hit/miss decision of the frame.
+"""
+import numpy as np
+import pytest
+
+from conftest import SCENE2, SCENE5, SCENE8
+
+# scene -> (triangles, nodes, inner, leaves, packets@W16, packets@W8, packets@W4, leaf refs, largest leaf, max packets/leaf@W16)
+TREE_PINS = {
+    SCENE5: (4014, 188, 101, 87, 435, 820, 1597, 6243, 537, 34),
+    SCENE8: (4022, 144, None, None, 401, None, None, 5758, 746, 47),
+    SCENE2: (2012, 112, None, None, 223, None, None, 3073, 243, None),
+}
+
+
+@pytest.mark.parametrize("path", list(TREE_PINS))
+def test_tree_topology_matches_reference_measurements(ora, path):
+    tris, nodes, inner, leaves, p16, p8, p4, refs, maxleaf, maxpacks = TREE_PINS[path]
+    sc = ora.Scene(ora.load_crtscene(path))
+    a16 = ora.Accel(sc, ora.ACCEL_KD_SIMD, W=16)
+    box, link, leafrefs = a16.dump()
+    is_leaf = link[:, 2] >= 0
+    assert a16.num_triangles == tris
+    assert a16.num_nodes == nodes
+    assert a16.num_packets == p16
+    assert a16.num_leaf_refs == refs == len(leafrefs)
+    assert link[is_leaf, 3].max() == maxleaf
+    if inner is not None:
+        assert (~is_leaf).sum() == inner and is_leaf.sum() == leaves
+    if maxpacks is not None:
+        assert int(np.ceil(link[is_leaf, 3] / 16).max()) == maxpacks
+    if p8 is not None:
+        assert ora.Accel(sc, ora.ACCEL_KD_SIMD, W=8).num_packets == p8
+        assert ora.Accel(sc, ora.ACCEL_KD_SIMD, W=4).num_packets == p4
+
+
+def test_kd_tree_accel_with_leaf_64_has_the_simd_topology(ora):
+    """kd_tree_accel<F,eps,8,64> builds a tree identical to kd_tree_simd_accel's."""
+    sc = ora.Scene(ora.load_crtscene(SCENE5))
+    b1, l1, r1 = ora.Accel(sc, ora.ACCEL_KD_SIMD, W=16).dump()
+    b2, l2, r2 = ora.Accel(sc, ora.ACCEL_KD_SCALAR, max_leaf=64).dump()
+    assert np.array_equal(b1, b2) and np.array_equal(l1, l2) and np.array_equal(r1, r2)
+
+
+def test_config1_ray_count(ora):
+    """BASELINE config 1: 640x480 -> 307,200 primary + 129,335 secondary = 436,535 intersect calls."""
+    sc = ora.Scene(ora.load_crtscene(SCENE5))
+    for kind in (ora.ACCEL_KD_SIMD, ora.ACCEL_KD_SCALAR):
+        _, cn = ora.Accel(sc, kind).render(640, 480, 1, 5, 0)
+        assert cn["primary"] == 307_200
+        assert cn["rays"] == 436_535
+
+
+def test_config2_ray_count_and_per_ray_work(ora):
+    """BASELINE config 2: 2,073,600 + 652,885 = 2,726,485 intersect calls; 10.50 nodes, 6.3 boxes passed,
+    1.27 leaves, 5.116 W=16 packets per ray.
+    SURVEY also lists 682,292 hits; this restatement (fp-contract off) counts 682,299 — the survey measured with
+    clang's default contraction, under which a few dozen shadow-ray hit/miss decisions flip."""
+    sc = ora.Scene(ora.load_crtscene(SCENE5))
+    _, cn = ora.Accel(sc, ora.ACCEL_KD_SIMD, W=16).render(1920, 1080, 1, 5, 0)
+    assert cn["primary"] == 2_073_600
+    assert cn["rays"] == 2_726_485
+    assert abs(cn["hits"] - 682_292) <= 16
+    r = cn["rays"]
+    assert round(cn["nodes"] / r, 2) == 10.50
+    assert round(cn["boxpass"] / r, 1) == 6.3
+    assert round(cn["leaves"] / r, 2) == 1.27
+    assert round(cn["packets"] / r, 3) == 5.116
+    assert round(16 * cn["packets"] / r, 1) == 81.9
+
+
+def test_scene8_and_hw15_ray_counts(ora):
+    """scene8 1920x1080 spp1 depth 10: 11,920,196 intersect calls, 19.7 nodes / 13.2 passed / 3.66 leaves / 15.0 packets
+    per ray; hw15/scene2 spp1: 8.1 nodes, 4.13 packets per ray."""
+    sc8 = ora.Scene(ora.load_crtscene(SCENE8))
+    _, cn = ora.Accel(sc8, ora.ACCEL_KD_SIMD, W=16).render(1920, 1080, 1, 10, 0)
+    assert cn["rays"] == 11_920_196
+    r = cn["rays"]
+    assert round(cn["nodes"] / r, 1) == 19.7 and round(cn["boxpass"] / r, 1) == 13.2
+    assert round(cn["leaves"] / r, 2) == 3.66 and round(cn["packets"] / r, 1) == 15.0
+    sc2 = ora.Scene(ora.load_crtscene(SCENE2))
+    _, cn = ora.Accel(sc2, ora.ACCEL_KD_SIMD, W=16).render(1920, 1920, 1, 5, 0)
+    r = cn["rays"]
+    assert round(cn["nodes"] / r, 1) == 8.1 and round(cn["packets"] / r, 2) == 4.13
+
+
+def test_packet_width_does_not_change_the_frame(ora):
+    """the framebuffer is identical at W = 16, 8 and 4 (padding repeats a real triangle)."""
+    sc = ora.Scene(ora.load_crtscene(SCENE5))
+    frames = [ora.Accel(sc, ora.ACCEL_KD_SIMD, W=w).render(480, 270, 1, 5, 0)[0] for w in (16, 8, 4, 5)]
+    for f in frames[1:]:
+        assert np.array_equal(frames[0].view(np.uint32), f.view(np.uint32))
+
+
+@pytest.mark.parametrize("path,depth", [(SCENE5, 5), (SCENE8, 10), (SCENE2, 5)])
+def test_the_two_accels_differ_only_by_normalisation(ora, path, depth):
+    """kd_tree_accel and kd_tree_simd_accel render the same frame except for hit_normal normalisation;
+    the ray counts (every shading-relevant hit/miss decision) agree exactly."""
+    sc = ora.Scene(ora.load_crtscene(path))
+    f1, c1 = ora.Accel(sc, ora.ACCEL_KD_SIMD).render(480, 270, 1, depth, 0)
+    f2, c2 = ora.Accel(sc, ora.ACCEL_KD_SCALAR).render(480, 270, 1, depth, 0)
+    if path == SCENE5:
+        assert c1["rays"] == c2["rays"]   # no refractive surface: normalisation never changes a ray
+    else:
+        # a smooth refractive surface re-normalises hit_normal (render.hpp:253); normalising twice differs in the
+        # last bit from normalising once, which nudges a few refracted paths
+        assert abs(c1["rays"] - c2["rays"]) < 1e-3 * c1["rays"]
+    differing = (np.abs(f1 - f2).max(axis=2) > 1e-4).mean()
+    assert differing < 0.05
+
+
+def test_threads_do_not_change_the_frame(ora):
+    """spp=1 renders are bitwise equal across tile schedules; with the counter-based RNG so are spp>1/GI."""
+    sc = ora.Scene(ora.load_crtscene(SCENE2))
+    a = ora.Accel(sc, ora.ACCEL_KD_SIMD)
+    f1, c1 = a.render(96, 96, 4, 5, 1, n_threads=1)
+    f2, c2 = a.render(96, 96, 4, 5, 1, n_threads=7)
+    assert c1 == c2
+    assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32))
+
+
+def test_fresnel_by_multiplication_equals_pow(ora):
+    """render.hpp:300 evaluates 0.5*std::pow(x,5) in double; the restatement multiplies instead.  After rounding to
+    float the two agree on a dense sample of the argument range."""
+    x = np.linspace(0.0, 2.0, 2_000_001, dtype=np.float32).astype(np.float64)
+    a = (0.5 * np.power(x, 5)).astype(np.float32)
+    b = (0.5 * (x * x * x * x * x)).astype(np.float32)
+    assert (a != b).mean() < 1e-6
+
+
+def test_deterministic_sincos_is_accurate(ora):
+    ang = np.linspace(0.0, 2 * np.pi, 20001).astype(np.float32)
+    got = np.array([ora.sincos(float(a)) for a in ang[::20]])
+    ref = np.stack([np.sin(ang[::20].astype(np.float64)), np.cos(ang[::20].astype(np.float64))], axis=1)
+    assert np.max(np.abs(got - ref)) < 1.2e-7
+
+
+def test_urand01_is_uniform_and_keyed(ora):
+    v = np.array([ora.urand01(42, p, s, c) for p in range(40) for s in range(5) for c in range(5)])
+    assert v.min() >= 0.0 and v.max() < 1.0
+    assert abs(v.mean() - 0.5) < 0.03
+    assert len(np.unique(v)) > 0.99 * len(v)
+    assert ora.urand01(42, 7, 1, 3) == ora.urand01(42, 7, 1, 3) != ora.urand01(43, 7, 1, 3)
