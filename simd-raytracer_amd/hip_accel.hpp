@@ -1,0 +1,179 @@
+// hip_accel.hpp — header-only adapter that models the reference's `accelerator` concept
+// (render/accel/accel.hpp:8-12) on top of the rtk C-ABI (include/rtk.h).
+//
+// Drop it next to the reference's headers and change ONE line of src/main.cpp:
+//     using A = kd_tree_simd_accel<F, static_cast<F>(epsilon)>;      // src/main.cpp:37
+// to  using A = hip_accel<F, static_cast<F>(epsilon)>;
+// Everything the reference's callers need is here: a constructor from std::shared_ptr<const scene<F>>
+// (src/main.cpp:41, kd_tree_simd.hpp:100), the public `scene_ptr` member that render_frame / color_hit /
+// is_occluded dereference (render/render.hpp:21,113,136), and
+//     template <bool cull> std::optional<hit<F>> intersect(const ray3<F>&) const noexcept;
+// `intersect` is one synchronous one-ray launch (correct, slow — it exists so the reference's own CPU
+// render_frame can drive the GPU tree ray by ray).  The fast paths are `intersect_batch` (one ray per lane)
+// and `render_frame` (the whole render loop device-side, replacing render/render.hpp:18-108).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <variant>
+#include <vector>
+
+#include <raytracer/core/math/ray3.hpp>
+#include <raytracer/render/hit.hpp>
+#include <raytracer/scene/scene.hpp>
+
+#include "rtk.h"
+
+template <typename F, F eps, std::size_t max_depth = 8, std::size_t max_leaf_size = 64>
+struct hip_accel {
+    static_assert(std::is_same_v<F, float>, "the rtk engine computes in float (the reference instantiates F = float, src/main.cpp:36)");
+
+    std::shared_ptr<const scene<F>> scene_ptr;
+
+    explicit hip_accel(std::shared_ptr<const scene<F>> scene_ptr_, bool normalize_hit_normal = true, int device = -1)
+        : scene_ptr(std::move(scene_ptr_)) {
+        const scene<F> &sc = *scene_ptr;
+        // flatten scene<F> exactly as parse_scene_file laid it out (io/json/loader.hpp:235-265)
+        std::vector<int32_t> mesh_material, mesh_nverts, mesh_ntris, mat_kind, mat_smooth;
+        std::vector<float> vertices, mat_albedo, mat_ior, light_pos, light_intensity;
+        std::vector<uint32_t> indices;
+        for (const auto &mesh : sc.meshes) {
+            mesh_material.push_back(static_cast<int32_t>(mesh.material_idx));
+            mesh_nverts.push_back(static_cast<int32_t>(mesh.vertices.size()));
+            mesh_ntris.push_back(static_cast<int32_t>(mesh.triangles.size()));
+            for (const auto &v : mesh.vertices) { vertices.push_back(v.x); vertices.push_back(v.y); vertices.push_back(v.z); }
+            for (const auto &t : mesh.triangles)
+                for (int k = 0; k < 3; ++k) indices.push_back(static_cast<uint32_t>(t.vertex_indices[k]));
+            first_triangle_.push_back(n_triangles_);
+            n_triangles_ += mesh.triangles.size();
+        }
+        for (const auto &mv : sc.materials) {
+            float albedo[3] = {0.f, 0.f, 0.f};
+            float ior = 1.f;
+            int kind = RTK_MAT_DIFFUSE, smooth = 0;
+            std::visit([&](const auto &m) {
+                using M = std::decay_t<decltype(m)>;
+                smooth = m.smooth_shading ? 1 : 0;
+                if constexpr (std::is_same_v<M, diffuse_material<F>>) kind = RTK_MAT_DIFFUSE;
+                else if constexpr (std::is_same_v<M, reflective_material<F>>) kind = RTK_MAT_REFLECTIVE;
+                else if constexpr (std::is_same_v<M, refractive_material<F>>) { kind = RTK_MAT_REFRACTIVE; ior = m.ior; }
+                else if constexpr (std::is_same_v<M, constant_material<F>>) kind = RTK_MAT_CONSTANT;
+                else throw std::invalid_argument("hip_accel: texture materials are outside the accelerated path");
+                if constexpr (requires { m.albedo; }) { albedo[0] = m.albedo.red; albedo[1] = m.albedo.green; albedo[2] = m.albedo.blue; }
+            }, mv);
+            mat_kind.push_back(kind); mat_smooth.push_back(smooth); mat_ior.push_back(ior);
+            mat_albedo.insert(mat_albedo.end(), albedo, albedo + 3);
+        }
+        for (const auto &l : sc.lights) {
+            light_pos.push_back(l.position.x); light_pos.push_back(l.position.y); light_pos.push_back(l.position.z);
+            light_intensity.push_back(l.intensity);
+        }
+        rtk_scene_desc d{};
+        d.n_meshes = static_cast<int32_t>(mesh_material.size());
+        d.mesh_material = mesh_material.data(); d.mesh_nverts = mesh_nverts.data(); d.mesh_ntris = mesh_ntris.data();
+        d.vertices = vertices.data(); d.indices = indices.data();
+        d.n_materials = static_cast<int32_t>(mat_kind.size());
+        d.mat_kind = mat_kind.data(); d.mat_albedo = mat_albedo.data(); d.mat_ior = mat_ior.data(); d.mat_smooth = mat_smooth.data();
+        d.n_lights = static_cast<int32_t>(light_intensity.size());
+        d.light_pos = light_pos.data(); d.light_intensity = light_intensity.data();
+        d.cam_pos[0] = sc.viewpoint.position.x; d.cam_pos[1] = sc.viewpoint.position.y; d.cam_pos[2] = sc.viewpoint.position.z;
+        for (int i = 0; i < 9; ++i) d.cam_mat[i] = sc.viewpoint.matrix.m[static_cast<std::size_t>(i)];
+        d.background[0] = sc.config.background_color.red; d.background[1] = sc.config.background_color.green;
+        d.background[2] = sc.config.background_color.blue;
+        d.width = static_cast<int32_t>(sc.config.image_width); d.height = static_cast<int32_t>(sc.config.image_height);
+        d.bucket_size = static_cast<int32_t>(sc.config.bucket_size);
+
+        rtk_scene *rs = nullptr;
+        check(rtk_scene_create(&d, &rs));
+        rtk_accel_params ap{};
+        ap.max_depth = static_cast<int32_t>(max_depth); ap.max_leaf_size = static_cast<int32_t>(max_leaf_size);
+        ap.eps = eps; ap.normalize_hit_normal = normalize_hit_normal ? 1 : 0; ap.device = device;
+        rtk_accel *ra = nullptr;
+        const int rc = rtk_accel_build(rs, &ap, &ra);
+        rtk_scene_destroy(rs);                       // the accel keeps its own copy (as kd_tree_simd.hpp:106-107 does)
+        check(rc);
+        accel_ = std::shared_ptr<rtk_accel>(ra, rtk_accel_destroy);
+    }
+
+    // accel.template intersect<cull>(ray) — render/accel/accel.hpp:9-10
+    template <bool backface_culling>
+    [[nodiscard]] std::optional<hit<F>> intersect(const ray3<F> &ray) const noexcept {
+        rtk_ray r{{ray.origin.x, ray.origin.y, ray.origin.z}, {ray.direction.x, ray.direction.y, ray.direction.z}};
+        rtk_hit h{};
+        if (rtk_accel_intersect(accel_.get(), &r, 1, backface_culling ? 1 : 0, RTK_TRACE_AUTO, &h) != RTK_OK) return std::nullopt;
+        return to_hit(ray, h);
+    }
+
+    // one ray per lane; out[i] corresponds to rays[i]
+    template <bool backface_culling>
+    [[nodiscard]] std::vector<std::optional<hit<F>>> intersect_batch(const std::vector<ray3<F>> &rays) const {
+        std::vector<rtk_ray> in(rays.size());
+        for (std::size_t i = 0; i < rays.size(); ++i)
+            in[i] = rtk_ray{{rays[i].origin.x, rays[i].origin.y, rays[i].origin.z},
+                            {rays[i].direction.x, rays[i].direction.y, rays[i].direction.z}};
+        std::vector<rtk_hit> out(rays.size());
+        check(rtk_accel_intersect(accel_.get(), in.data(), in.size(), backface_culling ? 1 : 0, RTK_TRACE_AUTO, out.data()));
+        std::vector<std::optional<hit<F>>> res(rays.size());
+        for (std::size_t i = 0; i < rays.size(); ++i) res[i] = to_hit(rays[i], out[i]);
+        return res;
+    }
+
+    // render_frame<A,F>(accel, BUCKET_TILES) with the whole loop device-side; pixels [h][w] as in image<F>
+    [[nodiscard]] std::vector<std::vector<color<F>>> render_frame(const rtk_render_params &params, rtk_counters *counters = nullptr) const {
+        std::size_t n = 0;
+        check(rtk_render_output_floats(accel_.get(), &params, &n));
+        std::vector<float> rgb(n);
+        check(rtk_render_frame(accel_.get(), &params, rgb.data(), counters));
+        const std::size_t w = params.width > 0 ? static_cast<std::size_t>(params.width) : scene_ptr->config.image_width;
+        const std::size_t h = n / 3 / w;
+        std::vector<std::vector<color<F>>> px(h, std::vector<color<F>>(w));
+        for (std::size_t y = 0; y < h; ++y)
+            for (std::size_t x = 0; x < w; ++x)
+                px[y][x] = color<F>{rgb[(y * w + x) * 3], rgb[(y * w + x) * 3 + 1], rgb[(y * w + x) * 3 + 2]};
+        return px;
+    }
+
+    // config.hpp:6-17 defaults
+    [[nodiscard]] static rtk_render_params default_params() noexcept {
+        rtk_render_params p{};
+        p.spp = 1; p.max_ray_depth = 5; p.diffuse_rays = 0; p.seed = 42; p.fov_degrees = 90.0;
+        p.shadow_bias = 1e-4f; p.reflection_bias = 1e-4f; p.refraction_bias = 1e-4f;
+        p.trace_mode = RTK_TRACE_AUTO; p.world_size = 1;
+        return p;
+    }
+
+    [[nodiscard]] rtk_accel *handle() const noexcept { return accel_.get(); }
+
+private:
+    std::shared_ptr<rtk_accel> accel_;
+    std::vector<std::size_t> first_triangle_;     // global triangle index of each mesh's first triangle
+    std::size_t n_triangles_ = 0;
+
+    static void check(int rc) {
+        if (rc != RTK_OK) throw std::runtime_error(std::string("rtk: ") + rtk_last_error());
+    }
+
+    // rebuilds hit<F> (render/hit.hpp:9-21) from the compact record, as kd_tree_simd.hpp:252-263 fills it
+    [[nodiscard]] std::optional<hit<F>> to_hit(const ray3<F> &ray, const rtk_hit &h) const noexcept {
+        if (h.tri == 0xFFFFFFFFu) return std::nullopt;
+        const auto &mesh = scene_ptr->meshes[h.mesh];
+        const auto &tri = mesh.triangles[h.tri - first_triangle_[h.mesh]];
+        return hit<F>{
+            ray,
+            ray.origin + (h.t * ray.direction),
+            vec3<F>{h.normal[0], h.normal[1], h.normal[2]},
+            tri.normal,
+            tri.uvs,
+            h.t,
+            h.u,
+            h.v,
+            static_cast<F>(1.) - h.u - h.v,
+            static_cast<std::size_t>(h.mesh)
+        };
+    }
+};
