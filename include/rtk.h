@@ -39,11 +39,13 @@ enum {
 /* material kinds: scene/material/material.hpp:12 (texture_material is out of scope) */
 enum { RTK_MAT_DIFFUSE = 0, RTK_MAT_REFLECTIVE = 1, RTK_MAT_REFRACTIVE = 2, RTK_MAT_CONSTANT = 3 };
 
-/* traversal strategy of the device kernels; all three give bit-identical results */
+/* traversal strategy of the device kernels; all of them give bit-identical results */
 enum {
     RTK_TRACE_AUTO = 0,   /* wave-cooperative while the wave's rays agree, per-lane otherwise */
     RTK_TRACE_LANE = 1,   /* one ray per lane, independent stackless traversal */
-    RTK_TRACE_WAVE = 2    /* one wave walks the tree once for its 64 rays (scalar node/triangle fetch) */
+    RTK_TRACE_WAVE = 2,   /* one wave walks the tree once for its 64 rays (scalar node/triangle fetch) */
+    RTK_TRACE_GROUP4 = 3, /* frames only: 4 waves share 64 rays and split every large leaf 4 ways (merge through LDS) */
+    RTK_TRACE_GROUP8 = 4  /* frames only: same with 8 waves */
 };
 
 typedef struct rtk_scene rtk_scene;   /* replaces scene<F>, scene/scene.hpp:14-22 */

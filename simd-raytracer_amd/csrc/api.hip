@@ -103,6 +103,7 @@ dev::TreeView tree_view(const rtk_accel *a) {
 }
 
 bool valid_mode(int m) { return m == RTK_TRACE_AUTO || m == RTK_TRACE_LANE || m == RTK_TRACE_WAVE; }
+bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || m == RTK_TRACE_GROUP8; }
 
 struct FrameGeom {
     uint32_t width, height, bucket, tiles_x, tiles_y, n_buckets, blocks_side, buckets_per_rank;
@@ -118,7 +119,7 @@ int frame_geom(const rtk_accel *a, const rtk_render_params *p, FrameGeom &g) {
     if (p->max_ray_depth < 0 || p->max_ray_depth > kMaxRayDepth)
         return fail(RTK_ERR_INVALID, "max_ray_depth must be in [0, 16]");
     if (p->diffuse_rays < 0 || p->diffuse_rays > 32767) return fail(RTK_ERR_INVALID, "diffuse_rays must be in [0, 32767]");
-    if (!valid_mode(p->trace_mode)) return fail(RTK_ERR_INVALID, "unknown trace_mode");
+    if (!valid_frame_mode(p->trace_mode)) return fail(RTK_ERR_INVALID, "unknown trace_mode");
     g.world = p->world_size > 1 ? p->world_size : 1;
     g.rank = p->world_size > 1 ? p->rank : 0;
     if (g.rank < 0 || g.rank >= g.world) return fail(RTK_ERR_INVALID, "rank must be in [0, world_size)");

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
         r = make_ray(mk(0.f, 0.f, 0.f), mk(1.f, 1.f, 1.f));
     }
     Stats st = {0, 0, 0, 0, 0, 0};
-    const Cand c = trace<MODE, STATS, LDS_NODES>(A.tree, lds_nodes, r, A.cull != 0, active, st);
+    SliceCtx sx = {nullptr, 0u, 0u};
+    const Cand c = trace<MODE, STATS, LDS_NODES>(A.tree, lds_nodes, r, A.cull != 0, active, st, sx);
     if (active) {
         float4 o0, o1;
         if (c.k != kMiss) {
@@ -138,15 +139,21 @@ struct Frame {            // 14 dwords, lives in scratch; touched only at refrac
     uint32_t tri;
 };
 
-template <int MODE, bool STATS, bool FORKS, bool LDS_NODES>
-__global__ __launch_bounds__(256) void k_render(RenderArgs A) {
+template <int MODE, bool STATS, bool FORKS, bool LDS_NODES, int SLICES>
+__global__ __launch_bounds__(SLICES > 4 ? 64 * SLICES : 256, SLICES > 4 ? 2 : 4) void k_render(RenderArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
-    if (LDS_NODES) stage_nodes(A.tree.nodes, A.tree.n_nodes, lds_nodes);
+    // the per-lane path reads nodes from LDS; the wave-cooperative paths fetch them with scalar loads instead
+    constexpr bool kStage = LDS_NODES && (MODE == RTK_TRACE_LANE || MODE == RTK_TRACE_AUTO);
+    if (kStage) stage_nodes(A.tree.nodes, A.tree.n_nodes, lds_nodes);
+    __shared__ float4 xbuf[SLICES > 1 ? 2 * SLICES * 64 : 1];
+    SliceCtx sx = {xbuf, SLICES > 1 ? (threadIdx.x >> 6) : 0u, 0u};
 
-    // ---- pixel assignment (tile/bucket.hpp:7-21 buckets, 8x8 blocks inside, round-robin over ranks)
+    // ---- pixel assignment (tile/bucket.hpp:7-21 buckets, 8x8 blocks inside, round-robin over ranks).
+    // SLICES > 1: all waves of the workgroup take the SAME 8x8 block (workgroup-cooperative leaves, trace.hip.hpp).
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t gwave = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const bool writer = (SLICES == 1) || (sx.slice == 0u);
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
     const uint32_t local_bucket = gwave / bpb, sub = gwave % bpb;
     const uint32_t bucket = (uint32_t)A.rank + local_bucket * (uint32_t)A.world;
@@ -157,6 +164,10 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
     const uint32_t px = bx + lx, py = by + ly;
     valid = valid & (lx < A.bucket) & (ly < A.bucket) & (px < A.width) & (py < A.height);
 
+#ifdef RTK_DEBUG_WAVE_TIME
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t dbg_iters = 0;
+#endif
     const V3 background = mk(A.background[0], A.background[1], A.background[2]);
     const V3 black = mk(0.f, 0.f, 0.f);
     const float PI_F = 3.14159265358979323846f;
@@ -187,8 +198,10 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
             if (state == ST_NEW_SAMPLE) {                                   // render.hpp:35-69
                 if (sample == A.spp) {
                     const float inv = (float)A.spp;
-                    float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
-                    o[0] = pixel_sum.x / inv; o[1] = pixel_sum.y / inv; o[2] = pixel_sum.z / inv;   // render.hpp:72
+                    if (writer) {
+                        float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
+                        o[0] = pixel_sum.x / inv; o[1] = pixel_sum.y / inv; o[2] = pixel_sum.z / inv;   // render.hpp:72
+                    }
                     state = ST_DONE;
                     continue;
                 }
@@ -370,7 +383,10 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
         // ---------- one wave-wide closest-hit query for every lane that has a ray pending
         const bool need = (state == ST_TRACE);
         if (__ballot(need) == 0ull) break;
-        cand = trace<MODE, STATS, LDS_NODES>(A.tree, lds_nodes, ray, cull, need, st);
+        cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx);
+#ifdef RTK_DEBUG_WAVE_TIME
+        dbg_iters += 1;
+#endif
 
         // ---------- consume
         if (need) {
@@ -407,9 +423,16 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A) {
         }
     }
 
+#ifdef RTK_DEBUG_WAVE_TIME
+    if (valid && writer) {
+        const unsigned long long dbg_t1 = __builtin_amdgcn_s_memrealtime();
+        float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
+        o[0] = (float)(dbg_t0 & 0xFFFFFFull); o[1] = (float)(dbg_t1 & 0xFFFFFFull); o[2] = (float)dbg_iters;
+    }
+#endif
     const uint32_t total = wave_sum(nrays);
-    if (STATS) flush_stats(st, 0u, A.counters);
-    if (lane == 0u) atomicAdd(A.counters + 0, (unsigned long long)total);
+    if (STATS && writer) flush_stats(st, 0u, A.counters);
+    if (lane == 0u && writer) atomicAdd(A.counters + 0, (unsigned long long)total);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,20 +464,22 @@ hipError_t launch_intersect_m(const dev::IntersectArgs &A, bool lds, size_t lds_
     return hipGetLastError();
 }
 
-template <int MODE, bool STATS, bool FORKS>
+template <int MODE, bool STATS, bool FORKS, int SLICES>
 hipError_t launch_render_m(const dev::RenderArgs &A, unsigned blocks, bool lds, size_t lds_bytes, hipStream_t s) {
-    if (lds) hipLaunchKernelGGL((dev::k_render<MODE, STATS, FORKS, true>), dim3(blocks), dim3(256), lds_bytes, s, A);
-    else hipLaunchKernelGGL((dev::k_render<MODE, STATS, FORKS, false>), dim3(blocks), dim3(256), 0, s, A);
+    const unsigned threads = SLICES > 1 ? 64u * SLICES : 256u;
+    constexpr bool kNeedsNodes = (MODE == RTK_TRACE_LANE || MODE == RTK_TRACE_AUTO);
+    if (lds && kNeedsNodes) hipLaunchKernelGGL((dev::k_render<MODE, STATS, FORKS, true, SLICES>), dim3(blocks), dim3(threads), lds_bytes, s, A);
+    else hipLaunchKernelGGL((dev::k_render<MODE, STATS, FORKS, false, SLICES>), dim3(blocks), dim3(threads), 0, s, A);
     return hipGetLastError();
 }
 
-template <int MODE>
+template <int MODE, int SLICES>
 hipError_t launch_render_mode(const dev::RenderArgs &A, unsigned blocks, bool stats, bool forks, bool lds, size_t lds_bytes,
                               hipStream_t s) {
-    if (stats) return forks ? launch_render_m<MODE, true, true>(A, blocks, lds, lds_bytes, s)
-                            : launch_render_m<MODE, true, false>(A, blocks, lds, lds_bytes, s);
-    return forks ? launch_render_m<MODE, false, true>(A, blocks, lds, lds_bytes, s)
-                 : launch_render_m<MODE, false, false>(A, blocks, lds, lds_bytes, s);
+    if (stats) return forks ? launch_render_m<MODE, true, true, SLICES>(A, blocks, lds, lds_bytes, s)
+                            : launch_render_m<MODE, true, false, SLICES>(A, blocks, lds, lds_bytes, s);
+    return forks ? launch_render_m<MODE, false, true, SLICES>(A, blocks, lds, lds_bytes, s)
+                 : launch_render_m<MODE, false, false, SLICES>(A, blocks, lds, lds_bytes, s);
 }
 
 }  // namespace
@@ -479,13 +504,16 @@ hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool fo
     const size_t lds_bytes = (size_t)A.tree.n_nodes * sizeof(DevNode);
     const bool lds = lds_bytes <= kMaxNodeLdsBytes;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
-    const uint64_t waves = (uint64_t)A.buckets_per_rank * bpb;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
-    if (blocks == 0) return hipSuccess;
+    const uint64_t waves = (uint64_t)A.buckets_per_rank * bpb;          // one per 8x8 pixel block
+    if (waves == 0) return hipSuccess;
+    if (waves > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const unsigned packed = (unsigned)((waves + 3) / 4);                  // 4 pixel blocks per workgroup
     switch (mode) {
-        case RTK_TRACE_LANE: return launch_render_mode<RTK_TRACE_LANE>(A, blocks, stats, forks, lds, lds_bytes, s);
-        case RTK_TRACE_WAVE: return launch_render_mode<RTK_TRACE_WAVE>(A, blocks, stats, forks, lds, lds_bytes, s);
-        default: return launch_render_mode<RTK_TRACE_AUTO>(A, blocks, stats, forks, lds, lds_bytes, s);
+        case RTK_TRACE_LANE: return launch_render_mode<RTK_TRACE_LANE, 1>(A, packed, stats, forks, lds, lds_bytes, s);
+        case RTK_TRACE_WAVE: return launch_render_mode<RTK_TRACE_WAVE, 1>(A, packed, stats, forks, lds, lds_bytes, s);
+        case RTK_TRACE_GROUP4: return launch_render_mode<RTK_TRACE_WAVE, 4>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
+        case RTK_TRACE_GROUP8: return launch_render_mode<RTK_TRACE_WAVE, 8>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
+        default: return launch_render_mode<RTK_TRACE_AUTO, 1>(A, packed, stats, forks, lds, lds_bytes, s);
     }
 }
 

@@ -164,9 +164,74 @@ __device__ __forceinline__ void trace_lane_from(const TreeView &T, const DevNode
 // jumps past a node another lane is waiting for.  Nodes and triangles are fetched with scalar loads.
 // Lanes see exactly the node/triangle sequence they would see alone, so results are identical.
 // Returns the lanes' `next` so the caller can continue per-lane (hand-over) if it left early.
-template <bool STATS>
+__device__ __forceinline__ bool wave_any(const bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+struct TriS {      // one leaf reference held in SGPRs (wave-uniform)
+    float v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z;
+};
+__device__ __forceinline__ TriS load_tri_uniform(cptr_f32 tp) {
+    TriS t;
+    t.v0x = tp[0]; t.v0y = tp[1]; t.v0z = tp[2];
+    t.e1x = tp[3]; t.e1y = tp[4]; t.e1z = tp[5];
+    t.e2x = tp[6]; t.e2y = tp[7]; t.e2z = tp[8];
+    return t;
+}
+
+// Tests leaf references [lo, hi) of the leaf starting at `first` against the wave's rays (lanes with `pass`).
+// Software-pipelined: the scalar loads of triangle k+1 are issued before triangle k is tested, so scalar-cache /
+// L2 latency overlaps the arithmetic.  Same arithmetic as test_triangle, with wave-level early outs between stages.
+__device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t first, const uint32_t lo, const uint32_t hi,
+                                                const Ray &r, const bool cull, const float eps, const bool pass, Cand &best) {
+    if (lo >= hi) return;
+    cptr_f32 tp = tris + (size_t)first * 9;
+    TriS cur = load_tri_uniform(tp + (size_t)lo * 9);
+    for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t kn = (k + 1u < hi) ? k + 1u : k;                    // last iteration re-reads itself (stays in bounds)
+        const TriS nxt = load_tri_uniform(tp + (size_t)kn * 9);
+        const float pvx = r.d.y * cur.e2z - r.d.z * cur.e2y;
+        const float pvy = r.d.z * cur.e2x - r.d.x * cur.e2z;
+        const float pvz = r.d.x * cur.e2y - r.d.y * cur.e2x;
+        const float det = cur.e1x * pvx + cur.e1y * pvy + cur.e1z * pvz;
+        bool m = pass & (eps <= (cull ? det : __builtin_fabsf(det)));
+        if (wave_any(m)) {
+            const float inv_det = (1.0f / det);
+            const float tvx = r.o.x - cur.v0x, tvy = r.o.y - cur.v0y, tvz = r.o.z - cur.v0z;
+            const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv_det;
+            m = m & (0.0f <= u) & (u <= 1.0f);
+            if (wave_any(m)) {
+                const float qx = tvy * cur.e1z - tvz * cur.e1y;
+                const float qy = tvz * cur.e1x - tvx * cur.e1z;
+                const float qz = tvx * cur.e1y - tvy * cur.e1x;
+                const float v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv_det;
+                m = m & (0.0f <= v) & (u + v <= 1.0f);
+                if (wave_any(m)) {
+                    const float t = (cur.e2x * qx + cur.e2y * qy + cur.e2z * qz) * inv_det;
+                    m = m & (eps < t) & (t < best.t);
+                    if (m) { best.t = t; best.u = u; best.v = v; best.k = first + k; }
+                }
+            }
+        }
+        cur = nxt;
+    }
+}
+
+// Workgroup-cooperative leaves (SLICES > 1): the SLICES waves of a workgroup hold THE SAME 64 rays and walk the
+// tree in lock step (all decisions depend only on the rays and on `best`, which is kept identical).  A leaf with at
+// least kSliceMinTris triangles is cut into SLICES contiguous ranges, one per wave; the per-wave winners are merged
+// through LDS in slice order with a strict '<', which is exactly the sequential "earliest triangle with the
+// smallest t" rule.  This divides the longest dependency chain of a frame — one wave grinding through a
+// 500-triangle leaf — by SLICES.
+constexpr uint32_t kSliceMinTris = 24;
+
+struct SliceCtx {
+    float4 *xbuf;        // LDS, [2][SLICES][64] candidates
+    uint32_t slice;      // this wave's slice id
+    uint32_t parity;     // which half of xbuf the next exchange uses
+};
+
+template <bool STATS, int SLICES>
 __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, const bool cull, const bool active,
-                                               Cand &best, Stats &st, const uint32_t min_lanes) {
+                                               Cand &best, Stats &st, const uint32_t min_lanes, SliceCtx &sx) {
     const uint32_t end = T.n_nodes;
     uint32_t next = active ? 0u : end;
     uint32_t n = 0;
@@ -178,7 +243,7 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
         const float hi0 = __uint_as_float(np[3]), hi1 = __uint_as_float(np[4]), hi2 = __uint_as_float(np[5]);
         const uint32_t a = np[6], b = np[7];
         const bool part = (next == n);
-        const unsigned long long part_mask = __ballot(part);
+        const unsigned long long part_mask = __builtin_amdgcn_ballot_w64(part);
         if (part_mask == 0ull) {                                           // nobody is waiting here
             n = (b == DEV_INNER) ? a : n + 1;
             continue;
@@ -188,7 +253,7 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
         const bool box = slab(lo0, lo1, lo2, hi0, hi1, hi2, r, t_min);
         const bool pass = part & box & !(best.t < t_min);
         if (STATS) { st.nodes += part ? 1u : 0u; st.boxpass += pass ? 1u : 0u; }
-        const bool any_pass = __ballot(pass) != 0ull;
+        const bool any_pass = wave_any(pass);
         if (b == DEV_INNER) {
             if (part) next = pass ? n + 1 : a;
             n = any_pass ? n + 1 : a;
@@ -196,31 +261,22 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
             if (part) next = n + 1;
             if (any_pass) {
                 if (STATS && pass) { st.leaves += 1; st.tris += b; st.packets16 += (b + 15u) >> 4; }
-                cptr_f32 tp = tris + (size_t)a * 9;
-                for (uint32_t k = 0; k < b; ++k, tp += 9) {
-                    const float e2x = tp[6], e2y = tp[7], e2z = tp[8];
-                    const float e1x = tp[3], e1y = tp[4], e1z = tp[5];
-                    // same arithmetic as test_triangle, with wave-level early outs between the stages
-                    const float pvx = r.d.y * e2z - r.d.z * e2y;
-                    const float pvy = r.d.z * e2x - r.d.x * e2z;
-                    const float pvz = r.d.x * e2y - r.d.y * e2x;
-                    const float det = e1x * pvx + e1y * pvy + e1z * pvz;
-                    bool m = pass & (T.eps <= (cull ? det : __builtin_fabsf(det)));
-                    if (__ballot(m) == 0ull) continue;
-                    const float inv_det = (1.0f / det);
-                    const float tvx = r.o.x - tp[0], tvy = r.o.y - tp[1], tvz = r.o.z - tp[2];
-                    const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv_det;
-                    m = m & (0.0f <= u) & (u <= 1.0f);
-                    if (__ballot(m) == 0ull) continue;
-                    const float qx = tvy * e1z - tvz * e1y;
-                    const float qy = tvz * e1x - tvx * e1z;
-                    const float qz = tvx * e1y - tvy * e1x;
-                    const float v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv_det;
-                    m = m & (0.0f <= v) & (u + v <= 1.0f);
-                    if (__ballot(m) == 0ull) continue;
-                    const float t = (e2x * qx + e2y * qy + e2z * qz) * inv_det;
-                    m = m & (T.eps < t) & (t < best.t);
-                    if (m) { best.t = t; best.u = u; best.v = v; best.k = a + k; }
+                if (SLICES > 1 && b >= kSliceMinTris) {
+                    const uint32_t lo = (b * sx.slice) / (uint32_t)SLICES, hi = (b * (sx.slice + 1u)) / (uint32_t)SLICES;
+                    Cand mine = best;
+                    leaf_range_wave(tris, a, lo, hi, r, cull, T.eps, pass, mine);
+                    const uint32_t lane = __lane_id();
+                    float4 *xb = sx.xbuf + (size_t)sx.parity * (SLICES * 64);
+                    xb[sx.slice * 64u + lane] = make_float4(mine.t, mine.u, mine.v, __uint_as_float(mine.k));
+                    __syncthreads();
+#pragma unroll
+                    for (int s = 0; s < SLICES; ++s) {
+                        const float4 c = xb[(uint32_t)s * 64u + lane];
+                        if (c.x < best.t) { best.t = c.x; best.u = c.y; best.v = c.z; best.k = __float_as_uint(c.w); }
+                    }
+                    sx.parity ^= 1u;
+                } else {
+                    leaf_range_wave(tris, a, 0u, b, r, cull, T.eps, pass, best);
                 }
             }
             n = n + 1;
@@ -233,20 +289,20 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
 // (wave-cooperative while at least `kAutoMinLanes` rays share the node, then per-lane from where each ray stands).
 constexpr uint32_t kAutoMinLanes = 12;
 
-template <int MODE, bool STATS, bool LDS_NODES>
+template <int MODE, bool STATS, bool LDS_NODES, int SLICES = 1>
 __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_nodes, const Ray &r, const bool cull,
-                                      const bool active, Stats &st) {
+                                      const bool active, Stats &st, SliceCtx &sx) {
     Cand best;
     best.t = kFltMax; best.u = 0.0f; best.v = 0.0f; best.k = kMiss;
     if (MODE == RTK_TRACE_LANE) {
         trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, active ? 0u : T.n_nodes, best, st);
     } else if (MODE == RTK_TRACE_WAVE) {
-        if (__ballot(active) != 0ull) (void)trace_wave<STATS>(T, r, cull, active, best, st, 1u);
+        if (wave_any(active)) (void)trace_wave<STATS, SLICES>(T, r, cull, active, best, st, 1u, sx);
     } else {
-        const unsigned long long am = __ballot(active);
+        const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
         if (am != 0ull) {
             uint32_t next = active ? 0u : T.n_nodes;
-            if ((uint32_t)__popcll(am) >= kAutoMinLanes) next = trace_wave<STATS>(T, r, cull, active, best, st, kAutoMinLanes);
+            if ((uint32_t)__popcll(am) >= kAutoMinLanes) next = trace_wave<STATS, 1>(T, r, cull, active, best, st, kAutoMinLanes, sx);
             trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, next, best, st);
         }
     }

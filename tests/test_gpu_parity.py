@@ -12,7 +12,8 @@ from conftest import CONFIG_SCENES, SCENE2, SCENE5, SCENE8
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-MODES = {"auto": 0, "lane": 1, "wave": 2}
+MODES = {"auto": 0, "lane": 1, "wave": 2}                       # batched intersect
+FRAME_MODES = {**MODES, "group4": 3, "group8": 4}              # frames: + workgroup-cooperative leaves
 
 
 def _bits(a):
@@ -123,12 +124,12 @@ RENDER_CASES = [
 
 
 @pytest.mark.parametrize("case", RENDER_CASES, ids=[c[0] for c in RENDER_CASES])
-@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("mode", list(FRAME_MODES))
 def test_render_gate_a(rtk, ora, case, mode):
     """Gate A: HIP frame vs the kd_tree_simd_accel restatement — expect max|delta| = 0, require < 1e-4."""
     _, path, w, h, spp, depth, diffuse = case
     acc, oacc = _scene_pair(rtk, ora, path)
-    cfg = rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=depth, diffuse_rays=diffuse, trace_mode=MODES[mode])
+    cfg = rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=depth, diffuse_rays=diffuse, trace_mode=FRAME_MODES[mode])
     rgb, cn = acc.render_frame(cfg)
     ref, ocn = oacc.render(w, h, spp, depth, diffuse)
     assert cn["rays"] == ocn["rays"]
@@ -165,7 +166,7 @@ def test_work_counters_match_oracle(rtk, ora, scene, depth):
     """Per-ray work (nodes popped, boxes passed, leaves, triangles, W=16 packets) equals the CPU restatement's:
     the algorithmic-byte figure of the roofline is computed from these."""
     acc, oacc = _scene_pair(rtk, ora, CONFIG_SCENES[scene])
-    for mode in MODES.values():
+    for mode in FRAME_MODES.values():
         cfg = rtk.RenderConfig(width=320, height=184, max_ray_depth=depth, trace_mode=mode, collect_stats=True)
         _, cn = acc.render_frame(cfg)
         _, ocn = ora.Accel(oacc.scene, ora.ACCEL_KD_SIMD, W=16).render(320, 184, 1, depth, 0)
@@ -190,7 +191,7 @@ def test_full_size_properties_4k(rtk, ora):
     base, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h))
     again, _ = acc.render_frame(rtk.RenderConfig(width=w, height=h))
     assert np.array_equal(_bits(base), _bits(again))
-    for mode in (1, 2):
+    for mode in (1, 2, 3, 4):
         other, cn2 = acc.render_frame(rtk.RenderConfig(width=w, height=h, trace_mode=mode))
         assert cn2["rays"] == cn["rays"]
         assert np.array_equal(_bits(base), _bits(other))
