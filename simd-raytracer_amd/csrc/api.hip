@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -56,7 +57,7 @@ struct rtk_accel {
     rtk::DevShade *d_shade = nullptr;
     rtk::DevMaterial *d_materials = nullptr;
     rtk::DevLight *d_lights = nullptr;
-    unsigned long long *d_counters = nullptr;     // 8 x u64, rtk_counters order
+    unsigned long long *d_counters = nullptr;     // 8 x u64 in rtk_counters order + kRayCounterShards ray-count shards
     hipStream_t last_stream = nullptr;
     uint64_t last_primary = 0;
     bool last_stats = false;
@@ -87,8 +88,8 @@ int ensure_device(rtk_accel *a) {
     if ((rc = upload(a->tree.dev_shade, &a->d_shade)) != RTK_OK) return rc;
     if ((rc = upload(a->scene.materials, &a->d_materials)) != RTK_OK) return rc;
     if ((rc = upload(a->scene.lights, &a->d_lights)) != RTK_OK) return rc;
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->d_counters), 8 * sizeof(unsigned long long)));
-    RTK_HIP(hipMemset(a->d_counters, 0, 8 * sizeof(unsigned long long)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->d_counters), kCounterWords * sizeof(unsigned long long)));
+    RTK_HIP(hipMemset(a->d_counters, 0, kCounterWords * sizeof(unsigned long long)));
     a->on_device = true;
     return RTK_OK;
 }
@@ -330,7 +331,7 @@ int rtk_accel_intersect_stats(rtk_accel *a, const rtk_ray *d_rays, size_t n, int
     std::lock_guard<std::mutex> lock(a->mu);
     int rc = ensure_device(a);
     if (rc != RTK_OK) return rc;
-    RTK_HIP(hipMemsetAsync(a->d_counters, 0, 8 * sizeof(unsigned long long), nullptr));
+    RTK_HIP(hipMemsetAsync(a->d_counters, 0, kCounterWords * sizeof(unsigned long long), nullptr));
     rc = intersect_device_impl(a, d_rays, n, cull, mode, d_out, nullptr, true);
     if (rc != RTK_OK) return rc;
     unsigned long long h[8];
@@ -398,8 +399,10 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     A.blocks_per_bucket_side = g.blocks_side; A.buckets_per_rank = g.buckets_per_rank;
     A.rank = g.rank; A.world = g.world; A.compact = g.world > 1 ? 1 : 0;
     A.out = d_out; A.counters = a->d_counters;
+    A.slice_min_tris = kSliceMinTrisDefault;
+    if (const char *e = std::getenv("RTK_SLICE_MIN_TRIS")) { const int v = std::atoi(e); if (v > 0) A.slice_min_tris = uint32_t(v); }
     const bool forks = a->has_refractive || p->diffuse_rays > 0;
-    RTK_HIP(hipMemsetAsync(a->d_counters, 0, 8 * sizeof(unsigned long long), s));
+    RTK_HIP(hipMemsetAsync(a->d_counters, 0, kCounterWords * sizeof(unsigned long long), s));
     if (g.world > 1) {
         // buckets past the end of the frame (padding so that every rank has equal length) stay zero
         size_t nf = size_t(g.buckets_per_rank) * g.bucket * g.bucket * 3;
@@ -435,9 +438,10 @@ int rtk_render_last_counters(rtk_accel *a, rtk_counters *c) {
     if (!a->on_device) return fail(RTK_ERR_INVALID, "no frame has been rendered on this accel");
     RTK_HIP(hipSetDevice(a->device));
     RTK_HIP(hipStreamSynchronize(a->last_stream));
-    unsigned long long h[8];
+    unsigned long long h[kCounterWords];
     RTK_HIP(hipMemcpy(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     std::memset(c, 0, sizeof(*c));
+    for (int i = 0; i < kRayCounterShards; ++i) h[0] += h[8 + i];      // the frame kernel shards its ray counter
     c->rays = h[0]; c->primary = a->last_primary;
     if (a->last_stats) { c->hits = h[2]; c->nodes = h[3]; c->boxpass = h[4]; c->leaves = h[5]; c->tris = h[6]; c->packets16 = h[7]; }
     return RTK_OK;

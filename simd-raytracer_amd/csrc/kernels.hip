@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
         r = make_ray(mk(0.f, 0.f, 0.f), mk(1.f, 1.f, 1.f));
     }
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {nullptr, 0u, 0u};
+    SliceCtx sx = {nullptr, 0u, 0u, 0u};
     const Cand c = trace<MODE, STATS, LDS_NODES>(A.tree, lds_nodes, r, A.cull != 0, active, st, sx);
     if (active) {
         float4 o0, o1;
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(SLICES > 4 ? 64 * SLICES : 256, SLICES > 4 ? 2 : 4)
     constexpr bool kStage = LDS_NODES && (MODE == RTK_TRACE_LANE || MODE == RTK_TRACE_AUTO);
     if (kStage) stage_nodes(A.tree.nodes, A.tree.n_nodes, lds_nodes);
     __shared__ float4 xbuf[SLICES > 1 ? 2 * SLICES * 64 : 1];
-    SliceCtx sx = {xbuf, SLICES > 1 ? (threadIdx.x >> 6) : 0u, 0u};
+    // the slice id is wave-uniform: say so (readfirstlane) or the sliced leaf loop is compiled with per-lane loads
+    SliceCtx sx = {xbuf, SLICES > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u, 0u, A.slice_min_tris};
 
     // ---- pixel assignment (tile/bucket.hpp:7-21 buckets, 8x8 blocks inside, round-robin over ranks).
     // SLICES > 1: all waves of the workgroup take the SAME 8x8 block (workgroup-cooperative leaves, trace.hip.hpp).
@@ -432,7 +433,8 @@ __global__ __launch_bounds__(SLICES > 4 ? 64 * SLICES : 256, SLICES > 4 ? 2 : 4)
 #endif
     const uint32_t total = wave_sum(nrays);
     if (STATS && writer) flush_stats(st, 0u, A.counters);
-    if (lane == 0u && writer) atomicAdd(A.counters + 0, (unsigned long long)total);
+    // one no-return atomic per pixel block, spread over 64 words (a single word saturates near 88 atomics/us)
+    if (lane == 0u && writer) atomicAdd(A.counters + 8 + (gwave % (uint32_t)kRayCounterShards), (unsigned long long)total);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,6 +8,9 @@
 namespace rtk {
 
 constexpr int kMaxRayDepth = 16;                 // frame-stack capacity of the render kernel
+constexpr int kRayCounterShards = 64;              // k_render spreads its per-wave ray-count atomics over this many words
+constexpr int kCounterWords = 8 + kRayCounterShards;
+constexpr uint32_t kSliceMinTrisDefault = 12;    // GROUP modes: leaves below this are tested whole by every wave
 constexpr size_t kMaxNodeLdsBytes = 48 * 1024;   // node arrays up to this size are staged in LDS (1536 nodes)
 
 }  // namespace rtk
@@ -45,6 +48,7 @@ struct RenderArgs {
     uint32_t bucket, tiles_x, tiles_y, n_buckets, blocks_per_bucket_side;
     uint32_t buckets_per_rank;
     int rank, world;
+    uint32_t slice_min_tris;          // GROUP modes: smallest leaf that is split across the workgroup's waves
     int compact;                      // 1: out is [buckets_per_rank][bucket][bucket][3]; 0: out is [h][w][3]
     float *out;
     unsigned long long *counters;

@@ -183,11 +183,11 @@ __device__ __forceinline__ TriS load_tri_uniform(cptr_f32 tp) {
 __device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t first, const uint32_t lo, const uint32_t hi,
                                                 const Ray &r, const bool cull, const float eps, const bool pass, Cand &best) {
     if (lo >= hi) return;
-    cptr_f32 tp = tris + (size_t)first * 9;
-    TriS cur = load_tri_uniform(tp + (size_t)lo * 9);
+    cptr_f32 tp = tris + ((size_t)first + lo) * 9;
+    TriS cur = load_tri_uniform(tp);
     for (uint32_t k = lo; k < hi; ++k) {
-        const uint32_t kn = (k + 1u < hi) ? k + 1u : k;                    // last iteration re-reads itself (stays in bounds)
-        const TriS nxt = load_tri_uniform(tp + (size_t)kn * 9);
+        if (k + 1u < hi) tp += 9;                                          // last iteration re-reads itself (stays in bounds)
+        const TriS nxt = load_tri_uniform(tp);
         const float pvx = r.d.y * cur.e2z - r.d.z * cur.e2y;
         const float pvy = r.d.z * cur.e2x - r.d.x * cur.e2z;
         const float pvz = r.d.x * cur.e2y - r.d.y * cur.e2x;
@@ -217,16 +217,16 @@ __device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t fi
 
 // Workgroup-cooperative leaves (SLICES > 1): the SLICES waves of a workgroup hold THE SAME 64 rays and walk the
 // tree in lock step (all decisions depend only on the rays and on `best`, which is kept identical).  A leaf with at
-// least kSliceMinTris triangles is cut into SLICES contiguous ranges, one per wave; the per-wave winners are merged
+// least `min_tris` triangles is cut into SLICES contiguous ranges, one per wave; the per-wave winners are merged
 // through LDS in slice order with a strict '<', which is exactly the sequential "earliest triangle with the
 // smallest t" rule.  This divides the longest dependency chain of a frame — one wave grinding through a
 // 500-triangle leaf — by SLICES.
-constexpr uint32_t kSliceMinTris = 24;
 
 struct SliceCtx {
     float4 *xbuf;        // LDS, [2][SLICES][64] candidates
     uint32_t slice;      // this wave's slice id
     uint32_t parity;     // which half of xbuf the next exchange uses
+    uint32_t min_tris;   // leaves with fewer triangles are not worth an exchange: every wave tests them whole
 };
 
 template <bool STATS, int SLICES>
@@ -261,7 +261,7 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
             if (part) next = n + 1;
             if (any_pass) {
                 if (STATS && pass) { st.leaves += 1; st.tris += b; st.packets16 += (b + 15u) >> 4; }
-                if (SLICES > 1 && b >= kSliceMinTris) {
+                if (SLICES > 1 && b >= sx.min_tris) {
                     const uint32_t lo = (b * sx.slice) / (uint32_t)SLICES, hi = (b * (sx.slice + 1u)) / (uint32_t)SLICES;
                     Cand mine = best;
                     leaf_range_wave(tris, a, lo, hi, r, cull, T.eps, pass, mine);
