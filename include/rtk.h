@@ -45,7 +45,8 @@ enum {
     RTK_TRACE_LANE = 1,   /* one ray per lane, independent stackless traversal */
     RTK_TRACE_WAVE = 2,   /* one wave walks the tree once for its 64 rays (scalar node/triangle fetch) */
     RTK_TRACE_GROUP4 = 3, /* frames only: 4 waves share 64 rays and split every large leaf 4 ways (merge through LDS) */
-    RTK_TRACE_GROUP8 = 4  /* frames only: same with 8 waves */
+    RTK_TRACE_GROUP8 = 4, /* frames only: same with 8 waves */
+    RTK_TRACE_GROUP2 = 5  /* frames only: same with 2 waves */
 };
 
 typedef struct rtk_scene rtk_scene;   /* replaces scene<F>, scene/scene.hpp:14-22 */

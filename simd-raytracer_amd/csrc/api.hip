@@ -104,7 +104,7 @@ dev::TreeView tree_view(const rtk_accel *a) {
 }
 
 bool valid_mode(int m) { return m == RTK_TRACE_AUTO || m == RTK_TRACE_LANE || m == RTK_TRACE_WAVE; }
-bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || m == RTK_TRACE_GROUP8; }
+bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || m == RTK_TRACE_GROUP8 || m == RTK_TRACE_GROUP2; }
 
 struct FrameGeom {
     uint32_t width, height, bucket, tiles_x, tiles_y, n_buckets, blocks_side, buckets_per_rank;

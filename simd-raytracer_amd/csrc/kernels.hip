@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
         r = make_ray(mk(0.f, 0.f, 0.f), mk(1.f, 1.f, 1.f));
     }
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {nullptr, 0u, 0u, 0u};
+    SliceCtx sx = {nullptr, 0u, 0u, true};
     const Cand c = trace<MODE, STATS, LDS_NODES>(A.tree, lds_nodes, r, A.cull != 0, active, st, sx);
     if (active) {
         float4 o0, o1;
@@ -140,21 +140,26 @@ struct Frame {            // 14 dwords, lives in scratch; touched only at refrac
 };
 
 template <int MODE, bool STATS, bool FORKS, bool LDS_NODES, int SLICES>
-__global__ __launch_bounds__(SLICES > 4 ? 64 * SLICES : 256, SLICES > 4 ? 2 : 4) void k_render(RenderArgs A) {
+__global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4) void k_render(RenderArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
     // the per-lane path reads nodes from LDS; the wave-cooperative paths fetch them with scalar loads instead
     constexpr bool kStage = LDS_NODES && (MODE == RTK_TRACE_LANE || MODE == RTK_TRACE_AUTO);
     if (kStage) stage_nodes(A.tree.nodes, A.tree.n_nodes, lds_nodes);
-    __shared__ float4 xbuf[SLICES > 1 ? 2 * SLICES * 64 : 1];
-    // the slice id is wave-uniform: say so (readfirstlane) or the sliced leaf loop is compiled with per-lane loads
-    SliceCtx sx = {xbuf, SLICES > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u, 0u, A.slice_min_tris};
+    __shared__ GroupShared group_sh[1];
+    // the wave index is wave-uniform: say so (readfirstlane) or everything derived from it is compiled per-lane
+    const uint32_t slice = SLICES > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+    if (SLICES > 1 && slice != 0u) {                 // helper waves (trace.hip.hpp, "Workgroup-cooperative leaves")
+        group_helper_loop<SLICES>(A.tree, &group_sh[0], slice);
+        return;
+    }
+    SliceCtx sx = {SLICES > 1 ? &group_sh[0] : nullptr, A.slice_min_tris, 0u, true};
 
     // ---- pixel assignment (tile/bucket.hpp:7-21 buckets, 8x8 blocks inside, round-robin over ranks).
-    // SLICES > 1: all waves of the workgroup take the SAME 8x8 block (workgroup-cooperative leaves, trace.hip.hpp).
+    // SLICES > 1: the whole workgroup serves ONE 8x8 block (wave 0 owns the rays, the others help with big leaves).
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gwave = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const bool writer = (SLICES == 1) || (sx.slice == 0u);
+    constexpr bool writer = true;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
     const uint32_t local_bucket = gwave / bpb, sub = gwave % bpb;
     const uint32_t bucket = (uint32_t)A.rank + local_bucket * (uint32_t)A.world;
@@ -431,6 +436,7 @@ __global__ __launch_bounds__(SLICES > 4 ? 64 * SLICES : 256, SLICES > 4 ? 2 : 4)
         o[0] = (float)(dbg_t0 & 0xFFFFFFull); o[1] = (float)(dbg_t1 & 0xFFFFFFull); o[2] = (float)dbg_iters;
     }
 #endif
+    if (SLICES > 1) group_post_exit(&group_sh[0]);
     const uint32_t total = wave_sum(nrays);
     if (STATS && writer) flush_stats(st, 0u, A.counters);
     // one no-return atomic per pixel block, spread over 64 words (a single word saturates near 88 atomics/us)
@@ -515,6 +521,7 @@ hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool fo
         case RTK_TRACE_WAVE: return launch_render_mode<RTK_TRACE_WAVE, 1>(A, packed, stats, forks, lds, lds_bytes, s);
         case RTK_TRACE_GROUP4: return launch_render_mode<RTK_TRACE_WAVE, 4>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
         case RTK_TRACE_GROUP8: return launch_render_mode<RTK_TRACE_WAVE, 8>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
+        case RTK_TRACE_GROUP2: return launch_render_mode<RTK_TRACE_WAVE, 2>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
         default: return launch_render_mode<RTK_TRACE_AUTO, 1>(A, packed, stats, forks, lds, lds_bytes, s);
     }
 }

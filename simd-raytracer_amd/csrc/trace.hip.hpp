@@ -215,19 +215,66 @@ __device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t fi
     }
 }
 
-// Workgroup-cooperative leaves (SLICES > 1): the SLICES waves of a workgroup hold THE SAME 64 rays and walk the
-// tree in lock step (all decisions depend only on the rays and on `best`, which is kept identical).  A leaf with at
-// least `min_tris` triangles is cut into SLICES contiguous ranges, one per wave; the per-wave winners are merged
-// through LDS in slice order with a strict '<', which is exactly the sequential "earliest triangle with the
-// smallest t" rule.  This divides the longest dependency chain of a frame — one wave grinding through a
-// 500-triangle leaf — by SLICES.
+// Workgroup-cooperative leaves (SLICES > 1).  A workgroup of SLICES waves serves ONE 8x8 pixel block: wave 0 (the
+// owner) holds the 64 rays, runs the shading state machine and walks the tree; waves 1..SLICES-1 are helpers that
+// sleep at a workgroup barrier until the owner reaches a leaf with at least `min_tris` triangles.  The owner then
+// publishes (leaf range, per-lane best_t, pass/cull masks) in LDS, every wave tests one contiguous SLICES-th of the
+// leaf, and the owner merges the winners in slice order with a strict '<' — exactly the sequential "earliest
+// triangle with the smallest t" rule.  This divides the longest dependency chain of a frame (one wave grinding
+// through a 500-triangle leaf) by SLICES without replicating traversal or shading work.
+struct GroupShared {
+    float4 ray_o[64];            // origin xyz (w unused); rewritten only when the owner starts a new ray
+    float4 ray_d[64];            // direction xyz
+    float best_t[64];            // per-lane best t before the leaf
+    float4 result[8][64];        // winners of slices 1..SLICES-1: t,u,v,k
+    unsigned long long pass_mask, cull_mask;
+    uint32_t first, count;       // leaf references [first, first+count)
+    uint32_t kind;               // 0 = leaf, 1 = exit
+    uint32_t ray_gen;            // bumped whenever ray_o/ray_d change
+};
+enum : uint32_t { GROUP_LEAF = 0, GROUP_EXIT = 1 };
 
 struct SliceCtx {
-    float4 *xbuf;        // LDS, [2][SLICES][64] candidates
-    uint32_t slice;      // this wave's slice id
-    uint32_t parity;     // which half of xbuf the next exchange uses
-    uint32_t min_tris;   // leaves with fewer triangles are not worth an exchange: every wave tests them whole
+    GroupShared *sh;     // LDS (nullptr when SLICES == 1)
+    uint32_t min_tris;   // leaves with fewer triangles are tested by the owner alone
+    uint32_t ray_gen;    // owner: generation of the rays currently in LDS
+    bool rays_dirty;     // owner: the current ray is not in LDS yet
 };
+
+// helper waves: serve leaf slices until the owner posts GROUP_EXIT
+template <int SLICES>
+__device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared *sh, const uint32_t slice) {
+    cptr_f32 tris = (cptr_f32)(const void *)T.tris;
+    const uint32_t lane = __lane_id();
+    uint32_t my_gen = 0xFFFFFFFFu;
+    Ray r;
+    r.o = mk(0.f, 0.f, 0.f); r.d = mk(0.f, 0.f, 0.f); r.inv = mk(0.f, 0.f, 0.f);
+    for (;;) {
+        __syncthreads();                                                   // B1: a command is posted
+        const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->kind);
+        if (kind == GROUP_EXIT) break;
+        const uint32_t gen = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->ray_gen);
+        if (gen != my_gen) {
+            const float4 o = sh->ray_o[lane], d = sh->ray_d[lane];
+            r.o = mk(o.x, o.y, o.z); r.d = mk(d.x, d.y, d.z);
+            my_gen = gen;
+        }
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->first);
+        const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->count);
+        const unsigned long long pm = sh->pass_mask, cm = sh->cull_mask;
+        Cand mine;
+        mine.t = sh->best_t[lane]; mine.u = 0.f; mine.v = 0.f; mine.k = kMiss;
+        const uint32_t lo = (count * slice) / (uint32_t)SLICES, hi = (count * (slice + 1u)) / (uint32_t)SLICES;
+        leaf_range_wave(tris, first, lo, hi, r, ((cm >> lane) & 1ull) != 0ull, T.eps, ((pm >> lane) & 1ull) != 0ull, mine);
+        sh->result[slice][lane] = make_float4(mine.t, mine.u, mine.v, __uint_as_float(mine.k));
+        __syncthreads();                                                   // B2: results are in LDS
+    }
+}
+
+__device__ __forceinline__ void group_post_exit(GroupShared *sh) {
+    if (__lane_id() == 0u) sh->kind = GROUP_EXIT;
+    __syncthreads();
+}
 
 template <bool STATS, int SLICES>
 __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, const bool cull, const bool active,
@@ -262,19 +309,28 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
             if (any_pass) {
                 if (STATS && pass) { st.leaves += 1; st.tris += b; st.packets16 += (b + 15u) >> 4; }
                 if (SLICES > 1 && b >= sx.min_tris) {
-                    const uint32_t lo = (b * sx.slice) / (uint32_t)SLICES, hi = (b * (sx.slice + 1u)) / (uint32_t)SLICES;
-                    Cand mine = best;
-                    leaf_range_wave(tris, a, lo, hi, r, cull, T.eps, pass, mine);
+                    GroupShared *sh = sx.sh;
                     const uint32_t lane = __lane_id();
-                    float4 *xb = sx.xbuf + (size_t)sx.parity * (SLICES * 64);
-                    xb[sx.slice * 64u + lane] = make_float4(mine.t, mine.u, mine.v, __uint_as_float(mine.k));
-                    __syncthreads();
+                    if (sx.rays_dirty) {
+                        sh->ray_o[lane] = make_float4(r.o.x, r.o.y, r.o.z, 0.f);
+                        sh->ray_d[lane] = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
+                        sx.ray_gen += 1u;
+                        sx.rays_dirty = false;
+                    }
+                    sh->best_t[lane] = best.t;
+                    const unsigned long long pm = __builtin_amdgcn_ballot_w64(pass), cm = __builtin_amdgcn_ballot_w64(cull);
+                    if (lane == 0u) {
+                        sh->pass_mask = pm; sh->cull_mask = cm;
+                        sh->first = a; sh->count = b; sh->kind = GROUP_LEAF; sh->ray_gen = sx.ray_gen;
+                    }
+                    __syncthreads();                                       // B1: helpers start on their slices
+                    leaf_range_wave(tris, a, 0u, b / (uint32_t)SLICES, r, cull, T.eps, pass, best);
+                    __syncthreads();                                       // B2: helper results are in LDS
 #pragma unroll
-                    for (int s = 0; s < SLICES; ++s) {
-                        const float4 c = xb[(uint32_t)s * 64u + lane];
+                    for (int s = 1; s < SLICES; ++s) {
+                        const float4 c = sh->result[s][lane];
                         if (c.x < best.t) { best.t = c.x; best.u = c.y; best.v = c.z; best.k = __float_as_uint(c.w); }
                     }
-                    sx.parity ^= 1u;
                 } else {
                     leaf_range_wave(tris, a, 0u, b, r, cull, T.eps, pass, best);
                 }
@@ -294,6 +350,7 @@ __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_node
                                       const bool active, Stats &st, SliceCtx &sx) {
     Cand best;
     best.t = kFltMax; best.u = 0.0f; best.v = 0.0f; best.k = kMiss;
+    sx.rays_dirty = true;
     if (MODE == RTK_TRACE_LANE) {
         trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, active ? 0u : T.n_nodes, best, st);
     } else if (MODE == RTK_TRACE_WAVE) {

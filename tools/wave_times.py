@@ -21,6 +21,11 @@ assert rc == 0
 # one sample per 8x8 block (all lanes of a wave wrote the same values)
 t0 = rgb[::8, ::8, 0].astype(np.float64); t1 = rgb[::8, ::8, 1].astype(np.float64); it = rgb[::8, ::8, 2]
 t1 = np.where(t1 < t0, t1 + 2**24, t1)
+med = np.median(t0)
+wrap = t0 < med - 2**23
+t0 = np.where(wrap, t0 + 2**24, t0); t1 = np.where(wrap, t1 + 2**24, t1)
+wrap = t0 > med + 2**23
+t0 = np.where(wrap, t0 - 2**24, t0); t1 = np.where(wrap, t1 - 2**24, t1)
 base = t0.min(); start = (t0 - base) / 100.0; end = (t1 - base) / 100.0; dur = end - start   # microseconds (100 MHz)
 print("waves", dur.size, "kernel span us", end.max())
 print("dur us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max()))
