@@ -10,6 +10,7 @@
 #include <new>
 
 #include "kernels.hpp"
+#include "stream.hpp"
 
 namespace rtk {
 
@@ -58,6 +59,10 @@ struct rtk_accel {
     rtk::DevMaterial *d_materials = nullptr;
     rtk::DevLight *d_lights = nullptr;
     unsigned long long *d_counters = nullptr;     // 8 x u64 in rtk_counters order + kRayCounterShards ray-count shards
+    // streaming-pipeline workspace (grown on demand)
+    rtk::dev::StreamWs ws = {{nullptr, nullptr}, nullptr, nullptr, nullptr, nullptr};
+    size_t ws_pixels = 0, ws_lights = 0;
+    bool ws_sum = false;
     hipStream_t last_stream = nullptr;
     uint64_t last_primary = 0;
     bool last_stats = false;
@@ -103,8 +108,32 @@ dev::TreeView tree_view(const rtk_accel *a) {
     return t;
 }
 
+// (Re)allocates the streaming workspace for `pixels` output pixels.  Allocation synchronises the device, so it only
+// happens when a larger frame (or more lights / multi-sample) is requested than ever before on this accel.
+int ensure_stream_ws(rtk_accel *a, size_t pixels, size_t lights, bool need_sum) {
+    if (lights == 0) lights = 1;
+    if (pixels <= a->ws_pixels && lights <= a->ws_lights && (!need_sum || a->ws_sum)) return RTK_OK;
+    const size_t np = pixels > a->ws_pixels ? pixels : a->ws_pixels;
+    const size_t nl = lights > a->ws_lights ? lights : a->ws_lights;
+    const bool sum = need_sum || a->ws_sum;
+    RTK_HIP(hipDeviceSynchronize());
+    (void)hipFree(a->ws.path[0]); (void)hipFree(a->ws.path[1]); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
+    (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
+    a->ws = dev::StreamWs{{nullptr, nullptr}, nullptr, nullptr, nullptr, nullptr};
+    a->ws_pixels = 0; a->ws_lights = 0; a->ws_sum = false;
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.path[0]), np * sizeof(dev::PathRay)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.path[1]), np * sizeof(dev::PathRay)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.hits), np * sizeof(dev::HitRec)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.contrib), np * nl * sizeof(float2)));
+    if (sum) RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.sumbuf), np * 3 * sizeof(float)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.ctrl), dev::kCtrlWords * sizeof(uint32_t)));
+    a->ws_pixels = np; a->ws_lights = nl; a->ws_sum = sum;
+    return RTK_OK;
+}
+
 bool valid_mode(int m) { return m == RTK_TRACE_AUTO || m == RTK_TRACE_LANE || m == RTK_TRACE_WAVE; }
-bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || m == RTK_TRACE_GROUP8 || m == RTK_TRACE_GROUP2; }
+bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || m == RTK_TRACE_GROUP8 || m == RTK_TRACE_GROUP2 ||
+           m == RTK_TRACE_STREAM; }
 
 struct FrameGeom {
     uint32_t width, height, bucket, tiles_x, tiles_y, n_buckets, blocks_side, buckets_per_rank;
@@ -297,6 +326,8 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipSetDevice(a->device);
         (void)hipFree(a->d_nodes); (void)hipFree(a->d_tris); (void)hipFree(a->d_tri_ids); (void)hipFree(a->d_shade);
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
+        (void)hipFree(a->ws.path[0]); (void)hipFree(a->ws.path[1]); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
+        (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
     }
     delete a;
 }
@@ -408,8 +439,26 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         size_t nf = size_t(g.buckets_per_rank) * g.bucket * g.bucket * 3;
         RTK_HIP(hipMemsetAsync(d_out, 0, nf * sizeof(float), s));
     }
-    const hipError_t e = launch_render(A, p->trace_mode, p->collect_stats != 0, forks, s);
-    if (e != hipSuccess) return hip_fail(e, "launch k_render");
+    // fork-free scenes (no refraction, no GI) can be rendered by the streaming pipeline (stream.hip)
+    const bool stream = !forks && (p->trace_mode == RTK_TRACE_STREAM || p->trace_mode == RTK_TRACE_AUTO);
+    if (p->trace_mode == RTK_TRACE_STREAM && forks)
+        return fail(RTK_ERR_UNSUPPORTED, "RTK_TRACE_STREAM needs a scene without refractive materials and diffuse_rays == 0");
+    if (stream) {
+        const size_t out_pixels = (g.world > 1) ? size_t(g.buckets_per_rank) * g.bucket * g.bucket : size_t(g.width) * g.height;
+        rc = ensure_stream_ws(a, out_pixels, a->scene.lights.size(), p->spp > 1);
+        if (rc != RTK_OK) return rc;
+        dev::StreamArgs S;
+        S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0;
+        for (int sample = 0; sample < p->spp; ++sample) {
+            S.sample = sample;
+            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, s);
+            if (es != hipSuccess) return hip_fail(es, "launch streaming pipeline");
+        }
+    } else {
+        const hipError_t e = launch_render(A, p->trace_mode == RTK_TRACE_STREAM ? RTK_TRACE_AUTO : p->trace_mode,
+                                           p->collect_stats != 0, forks, s);
+        if (e != hipSuccess) return hip_fail(e, "launch k_render");
+    }
     a->last_stream = s;
     a->last_stats = p->collect_stats != 0;
     // primary rays of this rank: pixels of its buckets x spp

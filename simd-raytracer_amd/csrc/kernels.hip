@@ -5,6 +5,7 @@
 
 #include "kernels.hpp"
 #include "trace.hip.hpp"
+#include "common.hip.hpp"
 
 namespace rtk {
 namespace dev {
@@ -71,21 +72,6 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Counter-based RNG: the reference's thread_local minstd_rand (utils/rand.hpp:5-19) is seeded identically on
-// every thread and handed out by a racy tile queue, so its stream cannot be reproduced.  Here a
-// draw is a pure function of (seed, absolute pixel, sample, draw index): frames do not depend on the wave/bucket/
-// rank layout.  det_sincos is a fixed double-precision sin/cos (Cody-Waite + Taylor) standing in for
-// std::sin/std::cos(float) at render.hpp:160-167: integer and IEEE-double operations only, so a CPU
-// restatement of the same formula reproduces it bit for bit.
-__device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
-    const uint32_t s = x * 747796405u + 2891336453u;
-    const uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
-    return (w >> 22u) ^ w;
-}
-__device__ __forceinline__ float urand01(uint32_t seed_hash, uint32_t pixel, uint32_t sample, uint32_t counter) {
-    const uint32_t h = pcg_hash(counter + pcg_hash(sample + pcg_hash(pixel + seed_hash)));
-    return (float)(h >> 8) * (1.0f / 16777216.0f);
-}
 __device__ __noinline__ void det_sincos(float angle, float &s, float &c) {
     const double x = (double)angle;
     const double two_over_pi = 0.63661977236758134308;
@@ -212,23 +198,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
                     continue;
                 }
                 draws = 0;
-                float rx = (float)px, ry = (float)py;
-                if (A.spp == 1) { rx += 0.5f; ry += 0.5f; }
-                else {
-                    rx += urand01(seed_hash, pixel, (uint32_t)sample, draws++);
-                    ry += urand01(seed_hash, pixel, (uint32_t)sample, draws++);
-                }
-                const float ndc_x = rx / (float)A.width, ndc_y = ry / (float)A.height;
-                float sx = (2.0f * ndc_x) - 1.0f;
-                float sy = 1.0f - (2.0f * ndc_y);
-                sx *= A.aspect;
-                sx = (float)((double)sx * A.tan_half_fov);                  // render.hpp:55-57 (float *= double)
-                sy = (float)((double)sy * A.tan_half_fov);
-                const float *M = A.cam_mat;                                 // transpose(camera.matrix) * dir
-                V3 d = mk(M[0] * sx + M[3] * sy + M[6] * -1.0f, M[1] * sx + M[4] * sy + M[7] * -1.0f,
-                          M[2] * sx + M[5] * sy + M[8] * -1.0f);
-                d = normalized(d);
-                ray = make_ray(mk(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]), d);
+                ray = camera_ray(A, px, py, pixel, (uint32_t)sample, seed_hash, draws);
                 cull = true; depth = 0; pend = PEND_CHILD_BG; fsp = 0;
                 state = ST_TRACE;
             } else if (state == ST_SHADE) {                                 // color_hit, render.hpp:133-308

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 MODES = {"auto": 0, "lane": 1, "wave": 2}                       # batched intersect
-FRAME_MODES = {**MODES, "group4": 3, "group8": 4}              # frames: + workgroup-cooperative leaves
+FRAME_MODES = {**MODES, "group4": 3, "group8": 4, "group2": 5, "stream": 6}   # frames: + workgroup-cooperative leaves, streaming pipeline
 
 
 def _bits(a):
@@ -130,6 +130,12 @@ def test_render_gate_a(rtk, ora, case, mode):
     _, path, w, h, spp, depth, diffuse = case
     acc, oacc = _scene_pair(rtk, ora, path)
     cfg = rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=depth, diffuse_rays=diffuse, trace_mode=FRAME_MODES[mode])
+    if mode == "stream" and (path != SCENE5 or diffuse > 0):
+        # the streaming pipeline only takes fork-free scenes and says so instead of falling back silently
+        with pytest.raises(rtk.RtkError) as e:
+            acc.render_frame(cfg)
+        assert e.value.code == rtk.RTK_ERR_UNSUPPORTED
+        return
     rgb, cn = acc.render_frame(cfg)
     ref, ocn = oacc.render(w, h, spp, depth, diffuse)
     assert cn["rays"] == ocn["rays"]
@@ -166,7 +172,9 @@ def test_work_counters_match_oracle(rtk, ora, scene, depth):
     """Per-ray work (nodes popped, boxes passed, leaves, triangles, W=16 packets) equals the CPU restatement's:
     the algorithmic-byte figure of the roofline is computed from these."""
     acc, oacc = _scene_pair(rtk, ora, CONFIG_SCENES[scene])
-    for mode in FRAME_MODES.values():
+    for name, mode in FRAME_MODES.items():
+        if name == "stream" and scene != "scene5":
+            continue
         cfg = rtk.RenderConfig(width=320, height=184, max_ray_depth=depth, trace_mode=mode, collect_stats=True)
         _, cn = acc.render_frame(cfg)
         _, ocn = ora.Accel(oacc.scene, ora.ACCEL_KD_SIMD, W=16).render(320, 184, 1, depth, 0)
@@ -191,7 +199,7 @@ def test_full_size_properties_4k(rtk, ora):
     base, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h))
     again, _ = acc.render_frame(rtk.RenderConfig(width=w, height=h))
     assert np.array_equal(_bits(base), _bits(again))
-    for mode in (1, 2, 3, 4):
+    for mode in (1, 2, 3, 4, 5, 6):
         other, cn2 = acc.render_frame(rtk.RenderConfig(width=w, height=h, trace_mode=mode))
         assert cn2["rays"] == cn["rays"]
         assert np.array_equal(_bits(base), _bits(other))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick A/B of the three traversal strategies on the benchmark workload (no CPU baseline)
-for m in ${MODES:-1 2 0 3 4}; do
+for m in ${MODES:-1 2 3 6}; do
   python bench.py --steps ${STEPS:-50} --warmup 5 --no-cpu-baseline --trace-mode $m 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
