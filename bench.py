@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "hw09", "scene5.crtscene")
 WIDTH, HEIGHT, SPP, DEPTH, DIFFUSE = 1920, 1080, 1, 5, 0
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-TRACE_NAMES = {0: "auto", 1: "lane", 2: "wave", 3: "group4", 4: "group8", 5: "group2", 6: "stream", 7: "megakernel-auto"}
+TRACE_NAMES = {0: "auto", 1: "lane", 2: "wave", 3: "group4", 4: "group8", 5: "group2", 6: "stream", 7: "twopass"}
 
 
 def algorithmic_bytes(c: dict) -> int:
@@ -62,7 +62,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--trace-mode", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6])
+    ap.add_argument("--trace-mode", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

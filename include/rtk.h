@@ -48,8 +48,10 @@ enum {
     RTK_TRACE_GROUP4 = 3, /* frames only: 4 waves share 64 rays and split every large leaf 4 ways (merge through LDS) */
     RTK_TRACE_GROUP8 = 4, /* frames only: same with 8 waves */
     RTK_TRACE_GROUP2 = 5, /* frames only: same with 2 waves */
-    RTK_TRACE_STREAM = 6  /* frames only, scenes without refraction/GI: per-depth path / shadow / resolve kernels with
-                             compacted ray queues (stream.hip); RTK_TRACE_AUTO picks it whenever it applies */
+    RTK_TRACE_STREAM = 6, /* frames only, scenes without refraction/GI: per-depth path / shadow / resolve kernels with
+                             compacted ray queues (stream.hip) */
+    RTK_TRACE_TWOPASS = 7 /* frames only, spp == 1: camera-ray pass, then the GROUP4 shading pass over the pixel blocks
+                             sorted by estimated cost, most expensive first */
 };
 
 typedef struct rtk_scene rtk_scene;   /* replaces scene<F>, scene/scene.hpp:14-22 */

@@ -24,7 +24,7 @@ _LIB_PATH = os.path.join(_HERE, "librtk_hip.so")
 
 RTK_OK, RTK_ERR_INVALID, RTK_ERR_NO_DEVICE, RTK_ERR_HIP, RTK_ERR_IO, RTK_ERR_PARSE, RTK_ERR_UNSUPPORTED = range(7)
 MAT_DIFFUSE, MAT_REFLECTIVE, MAT_REFRACTIVE, MAT_CONSTANT = 0, 1, 2, 3
-TRACE_AUTO, TRACE_LANE, TRACE_WAVE, TRACE_GROUP4, TRACE_GROUP8, TRACE_GROUP2, TRACE_STREAM = 0, 1, 2, 3, 4, 5, 6
+TRACE_AUTO, TRACE_LANE, TRACE_WAVE, TRACE_GROUP4, TRACE_GROUP8, TRACE_GROUP2, TRACE_STREAM, TRACE_TWOPASS = 0, 1, 2, 3, 4, 5, 6, 7
 
 # every symbol include/rtk.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [

@@ -63,6 +63,11 @@ struct rtk_accel {
     rtk::dev::StreamWs ws = {{nullptr, nullptr}, nullptr, nullptr, nullptr, nullptr};
     size_t ws_pixels = 0, ws_lights = 0;
     bool ws_sum = false;
+    // two-pass workspace
+    float4 *tp_prim = nullptr;
+    uint32_t *tp_bins = nullptr;       // [kCostBins] counts, [1] n_listed
+    uint32_t *tp_bin_list = nullptr, *tp_order = nullptr;
+    size_t tp_pixels = 0, tp_tiles = 0;
     hipStream_t last_stream = nullptr;
     uint64_t last_primary = 0;
     bool last_stats = false;
@@ -131,9 +136,24 @@ int ensure_stream_ws(rtk_accel *a, size_t pixels, size_t lights, bool need_sum) 
     return RTK_OK;
 }
 
+int ensure_twopass_ws(rtk_accel *a, size_t pixels, size_t tiles) {
+    if (pixels <= a->tp_pixels && tiles <= a->tp_tiles) return RTK_OK;
+    const size_t np = pixels > a->tp_pixels ? pixels : a->tp_pixels, nt = tiles > a->tp_tiles ? tiles : a->tp_tiles;
+    RTK_HIP(hipDeviceSynchronize());
+    (void)hipFree(a->tp_prim); (void)hipFree(a->tp_bins); (void)hipFree(a->tp_bin_list); (void)hipFree(a->tp_order);
+    a->tp_prim = nullptr; a->tp_bins = nullptr; a->tp_bin_list = nullptr; a->tp_order = nullptr;
+    a->tp_pixels = 0; a->tp_tiles = 0;
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->tp_prim), np * sizeof(float4)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->tp_bins), (kCostBins + 1) * sizeof(uint32_t)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->tp_bin_list), size_t(kCostBins) * nt * sizeof(uint32_t)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->tp_order), nt * sizeof(uint32_t)));
+    a->tp_pixels = np; a->tp_tiles = nt;
+    return RTK_OK;
+}
+
 bool valid_mode(int m) { return m == RTK_TRACE_AUTO || m == RTK_TRACE_LANE || m == RTK_TRACE_WAVE; }
 bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || m == RTK_TRACE_GROUP8 || m == RTK_TRACE_GROUP2 ||
-           m == RTK_TRACE_STREAM; }
+           m == RTK_TRACE_STREAM || m == RTK_TRACE_TWOPASS; }
 
 struct FrameGeom {
     uint32_t width, height, bucket, tiles_x, tiles_y, n_buckets, blocks_side, buckets_per_rank;
@@ -328,6 +348,7 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
         (void)hipFree(a->ws.path[0]); (void)hipFree(a->ws.path[1]); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
         (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
+        (void)hipFree(a->tp_prim); (void)hipFree(a->tp_bins); (void)hipFree(a->tp_bin_list); (void)hipFree(a->tp_order);
     }
     delete a;
 }
@@ -443,17 +464,44 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     const bool stream = !forks && (p->trace_mode == RTK_TRACE_STREAM || p->trace_mode == RTK_TRACE_AUTO);
     if (p->trace_mode == RTK_TRACE_STREAM && forks)
         return fail(RTK_ERR_UNSUPPORTED, "RTK_TRACE_STREAM needs a scene without refractive materials and diffuse_rays == 0");
-    if (stream) {
+    const bool twopass = p->trace_mode == RTK_TRACE_TWOPASS;
+    if (twopass && p->spp != 1) return fail(RTK_ERR_UNSUPPORTED, "RTK_TRACE_TWOPASS needs spp == 1");
+    if (twopass) {
+        const size_t out_pixels = (g.world > 1) ? size_t(g.buckets_per_rank) * g.bucket * g.bucket : size_t(g.width) * g.height;
+        const size_t tiles = size_t(g.buckets_per_rank) * g.blocks_side * g.blocks_side;
+        rc = ensure_twopass_ws(a, out_pixels, tiles);
+        if (rc != RTK_OK) return rc;
+        A.prim = a->tp_prim; A.bin_count = a->tp_bins; A.n_listed = a->tp_bins + kCostBins; A.bin_list = a->tp_bin_list;
+        A.tile_order = a->tp_order; A.tile_cap = uint32_t(a->tp_tiles);
+        const hipError_t et = launch_twopass(A, p->collect_stats != 0, forks, s);
+        if (et != hipSuccess) return hip_fail(et, "launch two-pass frame");
+    } else if (stream) {
         const size_t out_pixels = (g.world > 1) ? size_t(g.buckets_per_rank) * g.bucket * g.bucket : size_t(g.width) * g.height;
         rc = ensure_stream_ws(a, out_pixels, a->scene.lights.size(), p->spp > 1);
         if (rc != RTK_OK) return rc;
         dev::StreamArgs S;
-        S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0;
+        S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0; S.auto_min_lanes = 12;
+        int slices = 4;
+        if (const char *e = std::getenv("RTK_STREAM_SLICES")) slices = std::atoi(e) > 1 ? 4 : 1;
         for (int sample = 0; sample < p->spp; ++sample) {
             S.sample = sample;
-            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, s);
+            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, slices, s);
             if (es != hipSuccess) return hip_fail(es, "launch streaming pipeline");
         }
+#ifdef RTK_DEBUG_WAVE_TIME
+        {
+            uint32_t h[dev::kCtrlWords];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, a->ws.ctrl, sizeof(h), hipMemcpyDeviceToHost);
+            const char *names[3] = {"path0", "path", "shadow"};
+            for (int st = 0; st < 3; ++st) for (int lv = 0; lv < 4; ++lv) {
+                const uint32_t *d = h + dev::kCtrlDebug + (st * 4 + lv) * 4;
+                if (d[2]) std::fprintf(stderr, "[dbg] %s level %d: units %u mean %.1f us max %.1f us, longest block %.1f us (queue path %u hits %u)\n",
+                                       names[st], lv, d[2], d[0] / 100.0 / d[2], d[1] / 100.0, d[3] / 100.0,
+                                       h[dev::kCtrlPathCount + lv], h[dev::kCtrlHitCount + lv]);
+            }
+        }
+#endif
     } else {
         const hipError_t e = launch_render(A, p->trace_mode == RTK_TRACE_STREAM ? RTK_TRACE_AUTO : p->trace_mode,
                                            p->collect_stats != 0, forks, s);

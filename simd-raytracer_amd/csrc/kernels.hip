@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
         r = make_ray(mk(0.f, 0.f, 0.f), mk(1.f, 1.f, 1.f));
     }
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {nullptr, 0u, 0u, true};
+    SliceCtx sx = {nullptr, 0u, 0u, true, 0u};
     const Cand c = trace<MODE, STATS, LDS_NODES>(A.tree, lds_nodes, r, A.cull != 0, active, st, sx);
     if (active) {
         float4 o0, o1;
@@ -125,8 +125,11 @@ struct Frame {            // 14 dwords, lives in scratch; touched only at refrac
     uint32_t tri;
 };
 
-template <int MODE, bool STATS, bool FORKS, bool LDS_NODES, int SLICES>
+template <int MODE, bool STATS, bool FORKS, bool LDS_NODES, int SLICES, bool PRIMED = false>
 __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4) void k_render(RenderArgs A) {
+    // PRIMED (second pass of a two-pass frame): pixel blocks come from tile_order (most expensive first) and the
+    // camera ray's hit is read from A.prim instead of being traced again
+    if (PRIMED && blockIdx.x >= *A.n_listed) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
     // the per-lane path reads nodes from LDS; the wave-cooperative paths fetch them with scalar loads instead
@@ -139,12 +142,13 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
         group_helper_loop<SLICES>(A.tree, &group_sh[0], slice);
         return;
     }
-    SliceCtx sx = {SLICES > 1 ? &group_sh[0] : nullptr, A.slice_min_tris, 0u, true};
+    SliceCtx sx = {SLICES > 1 ? &group_sh[0] : nullptr, A.slice_min_tris, 0u, true, 0u};
 
     // ---- pixel assignment (tile/bucket.hpp:7-21 buckets, 8x8 blocks inside, round-robin over ranks).
     // SLICES > 1: the whole workgroup serves ONE 8x8 block (wave 0 owns the rays, the others help with big leaves).
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gwave = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t gwave = PRIMED ? A.tile_order[blockIdx.x]
+                                  : (SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     constexpr bool writer = true;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
     const uint32_t local_bucket = gwave / bpb, sub = gwave % bpb;
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
     Stats st = {0, 0, 0, 0, 0, 0};
     Cand cand;
     cand.t = kFltMax; cand.u = cand.v = 0.f; cand.k = kMiss;
+    bool primed = false;
 
     for (;;) {
         // ---------- resolve: run each lane forward until it needs a ray traced (or is done)
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
                 draws = 0;
                 ray = camera_ray(A, px, py, pixel, (uint32_t)sample, seed_hash, draws);
                 cull = true; depth = 0; pend = PEND_CHILD_BG; fsp = 0;
+                primed = PRIMED;
                 state = ST_TRACE;
             } else if (state == ST_SHADE) {                                 // color_hit, render.hpp:133-308
                 if (depth == A.max_depth) { ret = background; state = ST_RETURN; continue; }   // :138-139
@@ -359,7 +365,17 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
         // ---------- one wave-wide closest-hit query for every lane that has a ray pending
         const bool need = (state == ST_TRACE);
         if (__ballot(need) == 0ull) break;
-        cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx);
+        if (PRIMED && wave_any(primed)) {
+            // first iteration of the pass: every pending ray is a camera ray whose hit the first pass already found
+            if (need) {
+                const float4 pc = A.prim[A.out_index(local_bucket, lx, ly, px, py)];
+                cand.t = pc.x; cand.u = pc.y; cand.v = pc.z; cand.k = __float_as_uint(pc.w);
+                nrays -= 1;                                                 // counted by the first pass
+            }
+            primed = false;
+        } else {
+            cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx);
+        }
 #ifdef RTK_DEBUG_WAVE_TIME
         dbg_iters += 1;
 #endif
@@ -411,6 +427,78 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
     if (STATS && writer) flush_stats(st, 0u, A.counters);
     // one no-return atomic per pixel block, spread over 64 words (a single word saturates near 88 atomics/us)
     if (lane == 0u && writer) atomicAdd(A.counters + 8 + (gwave % (uint32_t)kRayCounterShards), (unsigned long long)total);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two-pass frames, first pass: camera rays only.  One workgroup per 8x8 pixel block (owner wave + helpers, as in
+// k_render).  Stores each pixel's candidate, writes the background for blocks no ray hits, and files every other
+// block under a log-scale estimate of the work its shading will need, so that the second pass can start the most
+// expensive blocks first (longest-processing-time-first: the frame no longer ends waiting for a few heavy blocks
+// that happened to be dispatched last).
+template <bool STATS, int SLICES>
+__global__ __launch_bounds__(64 * SLICES, 8) void k_primary(RenderArgs A) {
+    __shared__ GroupShared group_sh[1];
+    const uint32_t slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (slice != 0u) { group_helper_loop<SLICES>(A.tree, &group_sh[0], slice); return; }
+    SliceCtx sx = {&group_sh[0], A.slice_min_tris, 0u, true, 0u};
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gwave = blockIdx.x;
+    const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
+    const uint32_t local_bucket = gwave / bpb, sub = gwave % bpb;
+    const uint32_t bucket = (uint32_t)A.rank + local_bucket * (uint32_t)A.world;
+    const uint32_t bx = (bucket % A.tiles_x) * A.bucket, by = (bucket / A.tiles_x) * A.bucket;
+    const uint32_t lx = (sub % A.blocks_per_bucket_side) * 8u + (lane & 7u);
+    const uint32_t ly = (sub / A.blocks_per_bucket_side) * 8u + (lane >> 3);
+    const uint32_t px = bx + lx, py = by + ly;
+    const bool valid = (bucket < A.n_buckets) & (lx < A.bucket) & (ly < A.bucket) & (px < A.width) & (py < A.height);
+    uint32_t draws = 0;
+    const Ray ray = camera_ray(A, px, py, py * A.width + px, 0u, pcg_hash(A.seed), draws);
+    Stats st = {0, 0, 0, 0, 0, 0};
+    const Cand c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, true, valid, st, sx);
+    group_post_exit(&group_sh[0]);
+
+    const size_t pix = A.out_index(local_bucket, lx, ly, px, py);
+    const bool hit = valid & (c.k != kMiss);
+    const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(hit);
+    if (hit_mask == 0ull) {                                        // nothing to shade: the block is finished here
+        if (valid) {
+            float *o = A.out + pix * 3;                             // (0 + background) / 1, render.hpp:68-72 with spp == 1
+            o[0] = (0.0f + A.background[0]) / 1.0f; o[1] = (0.0f + A.background[1]) / 1.0f; o[2] = (0.0f + A.background[2]) / 1.0f;
+        }
+    } else {
+        if (valid) A.prim[pix] = make_float4(c.t, c.u, c.v, __uint_as_float(c.k));
+        // cost estimate: (trace rounds the block's shading will need) x (work of this block's primary trace)
+        int kind = -1;
+        if (hit) kind = A.materials[A.tree.shade[A.tree.tri_ids[c.k]].material].kind;
+        const bool any_diffuse = wave_any(kind == RTK_MAT_DIFFUSE), any_mirror = wave_any(kind == RTK_MAT_REFLECTIVE),
+                   any_glass = wave_any(kind == RTK_MAT_REFRACTIVE);
+        const uint32_t lights = (uint32_t)A.n_lights + (uint32_t)A.diffuse_rays * 4u;
+        uint32_t rounds = 1u;
+        if (any_diffuse) rounds += lights;
+        if (any_mirror) rounds += 1u + lights;
+        if (any_glass) rounds += 4u * (1u + lights);
+        const float cost = (float)rounds * (float)(sx.work + 16u) * (float)__popcll(hit_mask);
+        uint32_t bin = (uint32_t)(__builtin_log2f(cost) * 2.0f);
+        bin = bin > (uint32_t)(kCostBins - 1) ? (uint32_t)(kCostBins - 1) : bin;
+        if (lane == 0u) {
+            const uint32_t slot = atomicAdd(A.bin_count + bin, 1u);
+            A.bin_list[(size_t)bin * A.tile_cap + slot] = gwave;
+        }
+    }
+    const uint32_t total = wave_sum(valid ? 1u : 0u);
+    if (STATS) flush_stats(st, 0u, A.counters);
+    if (lane == 0u && total != 0u) atomicAdd(A.counters + 8 + (gwave % (uint32_t)kRayCounterShards), (unsigned long long)total);
+}
+
+// Two-pass frames, between the passes: concatenates the cost bins, most expensive first.  One workgroup per bin.
+__global__ __launch_bounds__(256) void k_tile_order(RenderArgs A) {
+    const uint32_t bin = (uint32_t)(kCostBins - 1) - blockIdx.x;
+    uint32_t offset = 0;
+    for (uint32_t b = bin + 1u; b < (uint32_t)kCostBins; ++b) offset += A.bin_count[b];
+    const uint32_t n = A.bin_count[bin];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) A.tile_order[offset + i] = A.bin_list[(size_t)bin * A.tile_cap + i];
+    if (bin == 0u && threadIdx.x == 0u) *A.n_listed = offset + n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,6 +582,27 @@ hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool fo
         case RTK_TRACE_GROUP2: return launch_render_mode<RTK_TRACE_WAVE, 2>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
         default: return launch_render_mode<RTK_TRACE_AUTO, 1>(A, packed, stats, forks, lds, lds_bytes, s);
     }
+}
+
+// Two-pass frame (spp == 1): k_primary -> k_tile_order -> primed k_render, all on one stream.
+hipError_t launch_twopass(const dev::RenderArgs &A, bool stats, bool forks, hipStream_t s) {
+    const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
+    const uint64_t tiles = (uint64_t)A.buckets_per_rank * bpb;
+    if (tiles == 0) return hipSuccess;
+    if (tiles > A.tile_cap) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(A.bin_count, 0, (kCostBins + 1) * sizeof(uint32_t), s);      // + n_listed
+    if (e != hipSuccess) return e;
+    if (stats) hipLaunchKernelGGL((dev::k_primary<true, 4>), dim3((unsigned)tiles), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL((dev::k_primary<false, 4>), dim3((unsigned)tiles), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(dev::k_tile_order, dim3(kCostBins), dim3(256), 0, s, A);
+    if (stats) {
+        if (forks) hipLaunchKernelGGL((dev::k_render<RTK_TRACE_WAVE, true, true, false, 4, true>), dim3((unsigned)tiles), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((dev::k_render<RTK_TRACE_WAVE, true, false, false, 4, true>), dim3((unsigned)tiles), dim3(256), 0, s, A);
+    } else {
+        if (forks) hipLaunchKernelGGL((dev::k_render<RTK_TRACE_WAVE, false, true, false, 4, true>), dim3((unsigned)tiles), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((dev::k_render<RTK_TRACE_WAVE, false, false, false, 4, true>), dim3((unsigned)tiles), dim3(256), 0, s, A);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_assemble(const dev::AssembleArgs &A, hipStream_t s) {

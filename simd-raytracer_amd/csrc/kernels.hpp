@@ -10,6 +10,7 @@ namespace rtk {
 constexpr int kMaxRayDepth = 16;                 // frame-stack capacity of the render kernel
 constexpr int kRayCounterShards = 64;              // k_render spreads its per-wave ray-count atomics over this many words
 constexpr int kCounterWords = 8 + kRayCounterShards;
+constexpr int kCostBins = 64;                      // two-pass frames: log-scale cost bins for longest-first scheduling
 constexpr uint32_t kSliceMinTrisDefault = 12;    // GROUP modes: leaves below this are tested whole by every wave
 constexpr size_t kMaxNodeLdsBytes = 48 * 1024;   // node arrays up to this size are staged in LDS (1536 nodes)
 
@@ -52,6 +53,13 @@ struct RenderArgs {
     int compact;                      // 1: out is [buckets_per_rank][bucket][bucket][3]; 0: out is [h][w][3]
     float *out;
     unsigned long long *counters;
+    // two-pass frames (RTK_TRACE_TWOPASS): k_primary fills these, k_tile_order sorts, the primed k_render consumes
+    float4 *prim;                     // [output pixels] primary-ray candidate t,u,v,k
+    uint32_t *bin_count;              // [kCostBins] pixel blocks per cost bin
+    uint32_t *bin_list;               // [kCostBins][tile_cap] pixel-block ids per bin
+    uint32_t *tile_order;             // [tile_cap] pixel blocks with work, most expensive first
+    uint32_t *n_listed;               // number of entries in tile_order
+    uint32_t tile_cap;
 
     __device__ __forceinline__ size_t out_index(uint32_t local_bucket, uint32_t lx, uint32_t ly, uint32_t px,
                                                 uint32_t py) const {
@@ -69,6 +77,7 @@ struct AssembleArgs {
 
 hipError_t launch_intersect(const dev::IntersectArgs &A, int mode, bool stats, hipStream_t s);
 hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool forks, hipStream_t s);
+hipError_t launch_twopass(const dev::RenderArgs &A, bool stats, bool forks, hipStream_t s);
 hipError_t launch_assemble(const dev::AssembleArgs &A, hipStream_t s);
 
 }  // namespace rtk

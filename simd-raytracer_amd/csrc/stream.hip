@@ -77,12 +77,19 @@ __device__ __forceinline__ void add_rays(const StreamArgs &S, const Stats &st, c
 // ------------------------------------------------------------------------------------------------
 // k_path: LEVEL0 = camera rays, one wave per 8x8 pixel block (same bucket / rank mapping as k_render);
 // otherwise depth-`level` reflection rays from the queue, waves striding over groups of 64 rays.
-template <bool LEVEL0, bool STATS>
+template <bool LEVEL0, bool STATS, int SLICES>
 __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     const RenderArgs &A = S.r;
+    // SLICES > 1: the workgroup's wave 0 owns the rays, waves 1.. help with large leaves (trace.hip.hpp)
+    __shared__ GroupShared group_sh[1];
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (SLICES > 1 && wave_in_block != 0u) {
+        group_helper_loop<SLICES>(A.tree, &group_sh[0], wave_in_block);
+        return;
+    }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t gwave = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;    // work-unit id
+    const uint32_t n_waves = SLICES > 1 ? gridDim.x : gridDim.x * (blockDim.x >> 6);
     const V3 background = mk(A.background[0], A.background[1], A.background[2]);
     const uint32_t level = S.level;
     const uint32_t n_rays = LEVEL0 ? 0u : S.ws.ctrl[kCtrlPathCount + level];
@@ -90,10 +97,16 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     const PathRay *qin = S.ws.path[level & 1u];
     PathRay *qout = S.ws.path[(level + 1u) & 1u];
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {nullptr, 0u, 0u, true};
+    SliceCtx sx = {SLICES > 1 ? &group_sh[0] : nullptr, A.slice_min_tris, 0u, true, 0u};
     uint32_t nrays = 0;
 
+#ifdef RTK_DEBUG_WAVE_TIME
+    const unsigned long long dbg_b0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (uint32_t item = LEVEL0 ? 0u : gwave; item < n_items; item += n_waves) {
+#ifdef RTK_DEBUG_WAVE_TIME
+        const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         bool valid;
         uint32_t pix = 0;
         Ray ray;
@@ -119,8 +132,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
         }
         Cand c;
         c.t = kFltMax; c.u = c.v = 0.f; c.k = kMiss;
-        if (wave_any(valid)) (void)trace_wave<STATS, 1>(A.tree, ray, LEVEL0, valid, c, st, 1u, sx);
-        if (STATS && c.k != kMiss) st.hits += 1;
+        c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, LEVEL0, valid, st, sx);
         nrays += valid ? 1u : 0u;
 
         // ---- material switch (color_hit, render.hpp:133-308, fork-free subset)
@@ -165,28 +177,53 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
                 q[1] = make_float4(n_or_d.x, n_or_d.y, n_or_d.z, __uint_as_float(mat));
             }
         }
+#ifdef RTK_DEBUG_WAVE_TIME
+        if (lane == 0u && level < 4u) {
+            const uint32_t dt = (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_t0);
+            uint32_t *d = S.ws.ctrl + kCtrlDebug + ((LEVEL0 ? 0u : 1u) * 4u + level) * 4u;
+            atomicAdd(d + 0, dt); atomicMax(d + 1, dt); atomicAdd(d + 2, 1u);
+        }
+#endif
     }
+#ifdef RTK_DEBUG_WAVE_TIME
+    if (lane == 0u && level < 4u)
+        atomicMax(S.ws.ctrl + kCtrlDebug + ((LEVEL0 ? 0u : 1u) * 4u + level) * 4u + 3, (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_b0));
+#endif
+    if (SLICES > 1) group_post_exit(&group_sh[0]);
     add_rays(S, st, nrays, STATS, gwave);
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_shadow: item = (group of 64 shading points, light).  Light loop body of render.hpp:184-206 up to the
 // occlusion decision; the contribution is stored and summed in light order by k_resolve.
-template <bool STATS>
+template <bool STATS, int SLICES>
 __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     const RenderArgs &A = S.r;
+    // SLICES > 1: the workgroup's wave 0 owns the rays, waves 1.. help with large leaves (trace.hip.hpp)
+    __shared__ GroupShared group_sh[1];
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (SLICES > 1 && wave_in_block != 0u) {
+        group_helper_loop<SLICES>(A.tree, &group_sh[0], wave_in_block);
+        return;
+    }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t gwave = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;    // work-unit id
+    const uint32_t n_waves = SLICES > 1 ? gridDim.x : gridDim.x * (blockDim.x >> 6);
     const uint32_t n_hits = S.ws.ctrl[kCtrlHitCount + S.level];
     const uint32_t n_lights = (uint32_t)A.n_lights;
     const uint32_t n_items = ((n_hits + 63u) >> 6) * n_lights;
     const float PI_F = 3.14159265358979323846f;
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {nullptr, 0u, 0u, true};
+    SliceCtx sx = {SLICES > 1 ? &group_sh[0] : nullptr, A.slice_min_tris, 0u, true, 0u};
     uint32_t nrays = 0;
 
+#ifdef RTK_DEBUG_WAVE_TIME
+    const unsigned long long dbg_b0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (uint32_t item = gwave; item < n_items; item += n_waves) {
+#ifdef RTK_DEBUG_WAVE_TIME
+        const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         const uint32_t group = item / n_lights, k = item % n_lights;
         const uint32_t h = group * 64u + lane;
         const bool valid = h < n_hits;
@@ -205,12 +242,23 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         const Ray ray = make_ray(P + (A.shadow_bias * ld), ld);
         Cand c;
         c.t = kFltMax; c.u = c.v = 0.f; c.k = kMiss;
-        if (wave_any(shoot)) (void)trace_wave<STATS, 1>(A.tree, ray, false, shoot, c, st, 1u, sx);
-        if (STATS && c.k != kMiss) st.hits += 1;
+        c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, false, shoot, st, sx);
         nrays += shoot ? 1u : 0u;
         const bool clear = !shoot | (c.k == kMiss) | (radius < c.t);         // render.hpp:117 (no transmissive surface here)
         if (valid) S.ws.contrib[(size_t)h * n_lights + k] = make_float2(contrib, clear ? 1.0f : 0.0f);
+#ifdef RTK_DEBUG_WAVE_TIME
+        if (lane == 0u && S.level < 4u) {
+            const uint32_t dt = (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_t0);
+            uint32_t *d = S.ws.ctrl + kCtrlDebug + (2u * 4u + S.level) * 4u;
+            atomicAdd(d + 0, dt); atomicMax(d + 1, dt); atomicAdd(d + 2, 1u);
+        }
+#endif
     }
+#ifdef RTK_DEBUG_WAVE_TIME
+    if (lane == 0u && S.level < 4u)
+        atomicMax(S.ws.ctrl + kCtrlDebug + (2u * 4u + S.level) * 4u + 3, (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_b0));
+#endif
+    if (SLICES > 1) group_post_exit(&group_sh[0]);
     add_rays(S, st, nrays, STATS, gwave);
 }
 
@@ -241,7 +289,25 @@ __global__ __launch_bounds__(256) void k_resolve(StreamArgs S) {
 
 // ------------------------------------------------------------------------------------------------ launchers
 
-hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, hipStream_t s) {
+namespace {
+
+template <bool LEVEL0, int SLICES>
+void launch_path(const dev::StreamArgs &S, bool stats, unsigned units, hipStream_t s) {
+    const unsigned blocks = SLICES > 1 ? units : (units + 3) / 4, threads = SLICES > 1 ? 64u * SLICES : 256u;
+    if (stats) hipLaunchKernelGGL((dev::k_path<LEVEL0, true, SLICES>), dim3(blocks), dim3(threads), 0, s, S);
+    else hipLaunchKernelGGL((dev::k_path<LEVEL0, false, SLICES>), dim3(blocks), dim3(threads), 0, s, S);
+}
+template <int SLICES>
+void launch_shadow(const dev::StreamArgs &S, bool stats, unsigned units, hipStream_t s) {
+    const unsigned blocks = SLICES > 1 ? units : (units + 3) / 4, threads = SLICES > 1 ? 64u * SLICES : 256u;
+    if (stats) hipLaunchKernelGGL((dev::k_shadow<true, SLICES>), dim3(blocks), dim3(threads), 0, s, S);
+    else hipLaunchKernelGGL((dev::k_shadow<false, SLICES>), dim3(blocks), dim3(threads), 0, s, S);
+}
+
+}  // namespace
+
+// One sample of one frame.  `slices` = waves per 64-ray work unit (1 or 4).
+hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int slices, hipStream_t s) {
     dev::StreamArgs S = base;
     const dev::RenderArgs &A = S.r;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
@@ -250,21 +316,22 @@ hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, hipStre
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(S.ws.ctrl, 0, dev::kCtrlWords * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    const unsigned tile_blocks = (unsigned)((tiles + 3) / 4);
-    const unsigned persist_blocks = 2048;                     // 8192 waves: 8 per SIMD on 256 CUs
+    // queue-driven stages are persistent: a fixed number of work units' worth of waves stride over the queue
+    // (8 waves per SIMD on 256 CUs = 8192 waves)
+    const unsigned persist_units = slices > 1 ? 8192u / (unsigned)slices : 8192u;
     for (int level = 0; level <= A.max_depth; ++level) {
         S.level = (uint32_t)level;
         if (level == 0) {
-            if (stats) hipLaunchKernelGGL((dev::k_path<true, true>), dim3(tile_blocks), dim3(256), 0, s, S);
-            else hipLaunchKernelGGL((dev::k_path<true, false>), dim3(tile_blocks), dim3(256), 0, s, S);
+            if (slices > 1) launch_path<true, 4>(S, stats, (unsigned)tiles, s);
+            else launch_path<true, 1>(S, stats, (unsigned)tiles, s);
         } else {
-            if (stats) hipLaunchKernelGGL((dev::k_path<false, true>), dim3(persist_blocks), dim3(256), 0, s, S);
-            else hipLaunchKernelGGL((dev::k_path<false, false>), dim3(persist_blocks), dim3(256), 0, s, S);
+            if (slices > 1) launch_path<false, 4>(S, stats, persist_units, s);
+            else launch_path<false, 1>(S, stats, persist_units, s);
         }
-        if (level < A.max_depth && A.n_lights >= 0) {
+        if (level < A.max_depth) {
             if (A.n_lights > 0) {
-                if (stats) hipLaunchKernelGGL((dev::k_shadow<true>), dim3(persist_blocks), dim3(256), 0, s, S);
-                else hipLaunchKernelGGL((dev::k_shadow<false>), dim3(persist_blocks), dim3(256), 0, s, S);
+                if (slices > 1) launch_shadow<4>(S, stats, persist_units, s);
+                else launch_shadow<1>(S, stats, persist_units, s);
             }
             hipLaunchKernelGGL(dev::k_resolve, dim3(1024), dim3(256), 0, s, S);
         }

@@ -23,7 +23,8 @@ static_assert(sizeof(PathRay) == 32 && sizeof(HitRec) == 32, "queue records are 
 // control block (u32 words): queue fill counts per depth level
 constexpr uint32_t kCtrlPathCount = 0;                      // [kMaxRayDepth + 2]
 constexpr uint32_t kCtrlHitCount = kMaxRayDepth + 2;        // [kMaxRayDepth + 2]
-constexpr uint32_t kCtrlWords = 2 * (kMaxRayDepth + 2);
+constexpr uint32_t kCtrlDebug = 2 * (kMaxRayDepth + 2);      // -DRTK_DEBUG_WAVE_TIME: [stage 0..2][level 0..3]{sum, max, n, block max}
+constexpr uint32_t kCtrlWords = kCtrlDebug + 3 * 4 * 4;
 
 struct StreamWs {
     PathRay *path[2];       // ping-pong by level parity, capacity = pixels of this rank
@@ -38,10 +39,11 @@ struct StreamArgs {
     StreamWs ws;
     uint32_t level;
     int sample;
+    uint32_t auto_min_lanes;   // RTK_TRACE_AUTO: leave the wave-cooperative walk when fewer rays than this share a node
 };
 
 }  // namespace dev
 
-hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, hipStream_t s);
+hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int slices, hipStream_t s);
 
 }  // namespace rtk

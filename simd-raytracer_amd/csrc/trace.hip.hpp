@@ -239,6 +239,7 @@ struct SliceCtx {
     uint32_t min_tris;   // leaves with fewer triangles are tested by the owner alone
     uint32_t ray_gen;    // owner: generation of the rays currently in LDS
     bool rays_dirty;     // owner: the current ray is not in LDS yet
+    uint32_t work;       // wave-uniform tally of nodes stepped + triangles iterated (a cost estimate for scheduling)
 };
 
 // helper waves: serve leaf slices until the owner posts GROUP_EXIT
@@ -301,6 +302,7 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
         const bool pass = part & box & !(best.t < t_min);
         if (STATS) { st.nodes += part ? 1u : 0u; st.boxpass += pass ? 1u : 0u; }
         const bool any_pass = wave_any(pass);
+        sx.work += (any_pass && b != DEV_INNER) ? b + 2u : 2u;
         if (b == DEV_INNER) {
             if (part) next = pass ? n + 1 : a;
             n = any_pass ? n + 1 : a;
@@ -347,7 +349,7 @@ constexpr uint32_t kAutoMinLanes = 12;
 
 template <int MODE, bool STATS, bool LDS_NODES, int SLICES = 1>
 __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_nodes, const Ray &r, const bool cull,
-                                      const bool active, Stats &st, SliceCtx &sx) {
+                                      const bool active, Stats &st, SliceCtx &sx, const uint32_t auto_min = kAutoMinLanes) {
     Cand best;
     best.t = kFltMax; best.u = 0.0f; best.v = 0.0f; best.k = kMiss;
     sx.rays_dirty = true;
@@ -359,7 +361,7 @@ __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_node
         const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
         if (am != 0ull) {
             uint32_t next = active ? 0u : T.n_nodes;
-            if ((uint32_t)__popcll(am) >= kAutoMinLanes) next = trace_wave<STATS, 1>(T, r, cull, active, best, st, kAutoMinLanes, sx);
+            if ((uint32_t)__popcll(am) >= auto_min) next = trace_wave<STATS, 1>(T, r, cull, active, best, st, auto_min, sx);
             trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, next, best, st);
         }
     }

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 MODES = {"auto": 0, "lane": 1, "wave": 2}                       # batched intersect
-FRAME_MODES = {**MODES, "group4": 3, "group8": 4, "group2": 5, "stream": 6}   # frames: + workgroup-cooperative leaves, streaming pipeline
+FRAME_MODES = {**MODES, "group4": 3, "group8": 4, "group2": 5, "stream": 6, "twopass": 7}   # frames: + workgroup-cooperative leaves, streaming pipeline
 
 
 def _bits(a):
@@ -130,6 +130,11 @@ def test_render_gate_a(rtk, ora, case, mode):
     _, path, w, h, spp, depth, diffuse = case
     acc, oacc = _scene_pair(rtk, ora, path)
     cfg = rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=depth, diffuse_rays=diffuse, trace_mode=FRAME_MODES[mode])
+    if mode == "twopass" and spp != 1:
+        with pytest.raises(rtk.RtkError) as e:
+            acc.render_frame(cfg)
+        assert e.value.code == rtk.RTK_ERR_UNSUPPORTED
+        return
     if mode == "stream" and (path != SCENE5 or diffuse > 0):
         # the streaming pipeline only takes fork-free scenes and says so instead of falling back silently
         with pytest.raises(rtk.RtkError) as e:
@@ -199,7 +204,7 @@ def test_full_size_properties_4k(rtk, ora):
     base, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h))
     again, _ = acc.render_frame(rtk.RenderConfig(width=w, height=h))
     assert np.array_equal(_bits(base), _bits(again))
-    for mode in (1, 2, 3, 4, 5, 6):
+    for mode in (1, 2, 3, 4, 5, 6, 7):
         other, cn2 = acc.render_frame(rtk.RenderConfig(width=w, height=h, trace_mode=mode))
         assert cn2["rays"] == cn["rays"]
         assert np.array_equal(_bits(base), _bits(other))
