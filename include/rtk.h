@@ -42,7 +42,7 @@ enum { RTK_MAT_DIFFUSE = 0, RTK_MAT_REFLECTIVE = 1, RTK_MAT_REFRACTIVE = 2, RTK_
 /* traversal strategy of the device kernels; all of them give bit-identical results */
 enum {
     RTK_TRACE_AUTO = 0,   /* batched intersect: wave-cooperative while the wave's rays agree, per-lane otherwise;
-                             frames: the streaming pipeline when the scene is fork-free, else that megakernel */
+                             frames: RTK_TRACE_GROUP4 */
     RTK_TRACE_LANE = 1,   /* one ray per lane, independent stackless traversal */
     RTK_TRACE_WAVE = 2,   /* one wave walks the tree once for its 64 rays (scalar node/triangle fetch) */
     RTK_TRACE_GROUP4 = 3, /* frames only: 4 waves share 64 rays and split every large leaf 4 ways (merge through LDS) */

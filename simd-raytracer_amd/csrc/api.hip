@@ -461,7 +461,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         RTK_HIP(hipMemsetAsync(d_out, 0, nf * sizeof(float), s));
     }
     // fork-free scenes (no refraction, no GI) can be rendered by the streaming pipeline (stream.hip)
-    const bool stream = !forks && (p->trace_mode == RTK_TRACE_STREAM || p->trace_mode == RTK_TRACE_AUTO);
+    const bool stream = !forks && p->trace_mode == RTK_TRACE_STREAM;
     if (p->trace_mode == RTK_TRACE_STREAM && forks)
         return fail(RTK_ERR_UNSUPPORTED, "RTK_TRACE_STREAM needs a scene without refractive materials and diffuse_rays == 0");
     const bool twopass = p->trace_mode == RTK_TRACE_TWOPASS;
@@ -503,7 +503,8 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         }
 #endif
     } else {
-        const hipError_t e = launch_render(A, p->trace_mode == RTK_TRACE_STREAM ? RTK_TRACE_AUTO : p->trace_mode,
+        // RTK_TRACE_AUTO for frames: workgroup-cooperative leaves (fastest megakernel variant on every config scene)
+        const hipError_t e = launch_render(A, p->trace_mode == RTK_TRACE_AUTO ? RTK_TRACE_GROUP4 : p->trace_mode,
                                            p->collect_stats != 0, forks, s);
         if (e != hipSuccess) return hip_fail(e, "launch k_render");
     }

@@ -38,6 +38,15 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t *counter, const bool wa
     return base + lane_prefix(mask);
 }
 
+// Dynamic work distribution for the queue-driven (persistent) stages: a unit's first item is its own index, every
+// further item is drawn from an atomic ticket, so units that got cheap items simply come back for more and the
+// stage ends when the queue is empty instead of when the unluckiest static share is done.
+__device__ __forceinline__ uint32_t next_item(uint32_t *ticket, const uint32_t n_units) {
+    uint32_t t = 0u;
+    if (__lane_id() == 0u) t = atomicAdd(ticket, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + n_units;
+}
+
 // final_color += colour ; after the last sample: pixels[y][x] = final_color / spp   (render.hpp:66-74)
 __device__ __forceinline__ void emit_pixel(const StreamArgs &S, const uint32_t pix, const V3 ret) {
     V3 sum;
@@ -103,7 +112,8 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
 #ifdef RTK_DEBUG_WAVE_TIME
     const unsigned long long dbg_b0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (uint32_t item = LEVEL0 ? 0u : gwave; item < n_items; item += n_waves) {
+    for (uint32_t item = LEVEL0 ? 0u : gwave; item < n_items;
+         item = LEVEL0 ? n_items : next_item(S.ws.ctrl + kCtrlTicket + level, n_waves)) {
 #ifdef RTK_DEBUG_WAVE_TIME
         const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
 #ifdef RTK_DEBUG_WAVE_TIME
     const unsigned long long dbg_b0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    for (uint32_t item = gwave; item < n_items; item += n_waves) {
+    for (uint32_t item = gwave; item < n_items; item = next_item(S.ws.ctrl + kCtrlTicket + (kMaxRayDepth + 2) + S.level, n_waves)) {
 #ifdef RTK_DEBUG_WAVE_TIME
         const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
 #endif

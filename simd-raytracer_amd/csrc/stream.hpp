@@ -23,7 +23,8 @@ static_assert(sizeof(PathRay) == 32 && sizeof(HitRec) == 32, "queue records are 
 // control block (u32 words): queue fill counts per depth level
 constexpr uint32_t kCtrlPathCount = 0;                      // [kMaxRayDepth + 2]
 constexpr uint32_t kCtrlHitCount = kMaxRayDepth + 2;        // [kMaxRayDepth + 2]
-constexpr uint32_t kCtrlDebug = 2 * (kMaxRayDepth + 2);      // -DRTK_DEBUG_WAVE_TIME: [stage 0..2][level 0..3]{sum, max, n, block max}
+constexpr uint32_t kCtrlTicket = 2 * (kMaxRayDepth + 2);     // [2][kMaxRayDepth + 2] dynamic work-unit tickets (path, shadow)
+constexpr uint32_t kCtrlDebug = 4 * (kMaxRayDepth + 2);      // -DRTK_DEBUG_WAVE_TIME: [stage 0..2][level 0..3]{sum, max, n, block max}
 constexpr uint32_t kCtrlWords = kCtrlDebug + 3 * 4 * 4;
 
 struct StreamWs {
