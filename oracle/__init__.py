@@ -127,8 +127,12 @@ def _lib(fast: bool = False, isa: str | None = None):
     L.ora_render_frame.argtypes = [vp, C.POINTER(_RenderParams), vp, vp]
     L.ora_write_ppm.restype = C.c_size_t
     L.ora_write_ppm.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
-    L.ora_urand01.restype = C.c_float
-    L.ora_urand01.argtypes = [C.c_uint32] * 4
+    L.ora_root_key.restype = C.c_uint32
+    L.ora_root_key.argtypes = [C.c_uint32] * 3
+    L.ora_child_key.restype = C.c_uint32
+    L.ora_child_key.argtypes = [C.c_uint32] * 2
+    L.ora_urand_key.restype = C.c_float
+    L.ora_urand_key.argtypes = [C.c_uint32] * 2
     L.ora_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     _libs[key] = L
     return L
@@ -334,8 +338,16 @@ def write_ppm(rgb: np.ndarray) -> bytes:
     return buf.raw[:n]
 
 
-def urand01(seed, pixel, sample, counter) -> float:
-    return float(_lib().ora_urand01(seed, pixel, sample, counter))
+def root_key(seed, pixel, sample) -> int:
+    return int(_lib().ora_root_key(seed, pixel, sample))
+
+
+def child_key(key, child) -> int:
+    return int(_lib().ora_child_key(key, child))
+
+
+def urand_key(key, j) -> float:
+    return float(_lib().ora_urand_key(key, j))
 
 
 def sincos(angle: float):

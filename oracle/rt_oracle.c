@@ -550,10 +550,18 @@ static inline uint32_t pcg_hash(uint32_t x) {
     const uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
     return (w >> 22u) ^ w;
 }
-/* Replaces utils/rand.hpp:5-19 (thread_local minstd_rand seeded 42 on every thread — a race)
- * with a counter-based generator keyed by (seed, absolute pixel, sample, draw index): uniform in [0,1), 24 bits. */
-float ora_urand01(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter) {
-    const uint32_t h = pcg_hash(counter + pcg_hash(sample + pcg_hash(pixel + pcg_hash(seed))));
+/* Replaces utils/rand.hpp:5-19 (thread_local minstd_rand seeded 42 on every thread — a race) with a
+ * counter-based generator keyed by the POSITION OF A RAY IN ITS SAMPLE'S RAY TREE, not by the order in which a
+ * particular traversal happens to draw: root key = f(seed, absolute pixel, sample); a secondary ray's key is derived
+ * from its parent ray's key and its child index; draw j at a ray is a pure function of (key, j).  A recursive CPU
+ * evaluation, a per-lane GPU state machine and a level-by-level GPU wavefront therefore all see the same numbers.
+ * Uniform in [0,1), 24 bits. */
+uint32_t ora_root_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+    return pcg_hash(sample + pcg_hash(pixel + pcg_hash(seed)));
+}
+uint32_t ora_child_key(uint32_t key, uint32_t child) { return pcg_hash(key ^ (0x632BE5ABu * (child + 1u))); }
+float ora_urand_key(uint32_t key, uint32_t j) {
+    const uint32_t h = pcg_hash(key + j * 0x9E3779B9u + 0x85EBCA6Bu);
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
@@ -610,7 +618,6 @@ typedef struct {
 
 typedef struct {
     uint64_t cn[ORA_C_COUNT];
-    uint32_t pixel, sample, draws;      /* RNG key */
 } thread_ctx;
 
 typedef struct { float r, g, b; } col;
@@ -618,10 +625,6 @@ static inline col mkcol(float r, float g, float b) { col c = {r, g, b}; return c
 static inline col cadd(col a, col b) { return mkcol(a.r + b.r, a.g + b.g, a.b + b.b); }      /* color.hpp:9-14 */
 static inline col cscl(float s, col a) { return mkcol(s * a.r, s * a.g, s * a.b); }          /* color.hpp:35-41 */
 static inline col cdiv(col a, float s) { return mkcol(a.r / s, a.g / s, a.b / s); }          /* color.hpp:16-21 */
-
-static inline float next_rand(const frame_ctx *f, thread_ctx *t) {
-    return ora_urand01(f->p.seed, t->pixel, t->sample, t->draws++);
-}
 
 /* render.hpp:110-131 */
 static int is_occluded(const frame_ctx *f, thread_ctx *tc, ray3 ray, float max_t) {
@@ -638,7 +641,8 @@ static int is_occluded(const frame_ctx *f, thread_ctx *tc, ray3 ray, float max_t
 }
 
 /* render.hpp:133-308 */
-static col color_hit(const frame_ctx *f, thread_ctx *tc, const hit_rec *hr, int depth) {
+/* `key` is the RNG key of the ray that produced this hit */
+static col color_hit(const frame_ctx *f, thread_ctx *tc, const hit_rec *hr, int depth, uint32_t key) {
     const ora_scene *sc = f->accel->scene;
     const col background = mkcol(sc->background[0], sc->background[1], sc->background[2]);
     if (depth == f->p.max_depth) return background;                         /* :138-139 */
@@ -655,10 +659,10 @@ static col color_hit(const frame_ctx *f, thread_ctx *tc, const hit_rec *hr, int 
             const v3 right = norm3(cross3(in.direction, hn));
             const v3 up = hn;
             const v3 fwd = cross3(right, up);
-            const float a_xy = PI_F * next_rand(f, tc);
+            const float a_xy = PI_F * ora_urand_key(key, 2u + 2u * (uint32_t)i);
             float s1, c1; ora_sincos(a_xy, &s1, &c1);
             v3 rv = mk(c1, s1, 0.0f);
-            const float a_xz = PI_F * next_rand(f, tc) * 2.0f;
+            const float a_xz = PI_F * ora_urand_key(key, 3u + 2u * (uint32_t)i) * 2.0f;
             float s2, c2; ora_sincos(a_xz, &s2, &c2);
             /* rotate_y_mat * rand_xy_vec (mat3.hpp:53-60), rows {c,0,-s},{0,1,0},{s,0,c} */
             rv = mk(c2 * rv.x + 0.0f * rv.y + (-s2) * rv.z,
@@ -672,7 +676,7 @@ static col color_hit(const frame_ctx *f, thread_ctx *tc, const hit_rec *hr, int 
             const ray3 gr = mkray(org, dir);
             hit_rec gh;
             if (!accel_intersect(f->accel, &gr, 0, &gh, tc->cn)) continue;
-            final = cadd(final, color_hit(f, tc, &gh, depth + 1));
+            final = cadd(final, color_hit(f, tc, &gh, depth + 1, ora_child_key(key, (uint32_t)i)));
         }
         for (int li = 0; li < sc->n_lights; ++li) {                          /* :184-206 */
             const light *L = &sc->lights[li];
@@ -694,7 +698,7 @@ static col color_hit(const frame_ctx *f, thread_ctx *tc, const hit_rec *hr, int 
         const ray3 rr = mkray(ro, rd);
         hit_rec rh;
         if (!accel_intersect(f->accel, &rr, 0, &rh, tc->cn)) return background;
-        return color_hit(f, tc, &rh, depth + 1);
+        return color_hit(f, tc, &rh, depth + 1, ora_child_key(key, 0u));
     }
     case ORA_MAT_REFRACTIVE: {                                               /* :252-301 */
         v3 n = norm3(m->smooth ? hn : fn);
@@ -708,7 +712,7 @@ static col color_hit(const frame_ctx *f, thread_ctx *tc, const hit_rec *hr, int 
             const ray3 rr = mkray(add3(P, scl3(f->p.reflection_bias, rd)), rd);
             hit_rec rh;
             if (!accel_intersect(f->accel, &rr, 0, &rh, tc->cn)) return mkcol(0.f, 0.f, 0.f);
-            return color_hit(f, tc, &rh, depth + 1);
+            return color_hit(f, tc, &rh, depth + 1, ora_child_key(key, 0u));
         }
         const float sin_r = ((sin_i_n * eta_i) / eta_r);
         const float cos_r = sqrtf(1.0f - sin_r * sin_r);
@@ -716,12 +720,12 @@ static col color_hit(const frame_ctx *f, thread_ctx *tc, const hit_rec *hr, int 
         const ray3 fr = mkray(add3(P, scl3(f->p.refraction_bias, r)), r);
         hit_rec fh;
         col refr = mkcol(0.f, 0.f, 0.f);
-        if (accel_intersect(f->accel, &fr, 0, &fh, tc->cn)) refr = color_hit(f, tc, &fh, depth + 1);
+        if (accel_intersect(f->accel, &fr, 0, &fh, tc->cn)) refr = color_hit(f, tc, &fh, depth + 1, ora_child_key(key, 0u));
         const v3 rd = sub3(i, scl3(2.0f * dot3(i, n), n));
         const ray3 rr = mkray(add3(P, scl3(f->p.reflection_bias, rd)), rd);
         hit_rec rh;
         col refl = mkcol(0.f, 0.f, 0.f);
-        if (accel_intersect(f->accel, &rr, 0, &rh, tc->cn)) refl = color_hit(f, tc, &rh, depth + 1);
+        if (accel_intersect(f->accel, &rr, 0, &rh, tc->cn)) refl = color_hit(f, tc, &rh, depth + 1, ora_child_key(key, 1u));
         /* :300 — 0.5 * std::pow(float, int) is evaluated in double; x^5 by multiplication here and on the GPU */
         const double x = (double)(1.0f + dot3(i, n));
         const float fresnel = (float)(0.5 * (x * x * x * x * x));
@@ -742,12 +746,12 @@ static void render_tile(frame_ctx *f, thread_ctx *tc, int x0, int y0, int x1, in
     for (int y = y0; y < y1; ++y) {
         for (int x = x0; x < x1; ++x) {
             col final = mkcol(0.f, 0.f, 0.f);
-            tc->pixel = (uint32_t)y * (uint32_t)f->width + (uint32_t)x;
+            const uint32_t pixel = (uint32_t)y * (uint32_t)f->width + (uint32_t)x;
             for (int s = 0; s < f->p.spp; ++s) {
-                tc->sample = (uint32_t)s; tc->draws = 0;
+                const uint32_t key = ora_root_key(f->p.seed, pixel, (uint32_t)s);
                 float rx = (float)x, ry = (float)y;
                 if (f->p.spp == 1) { rx += 0.5f; ry += 0.5f; }
-                else { rx += next_rand(f, tc); ry += next_rand(f, tc); }
+                else { rx += ora_urand_key(key, 0u); ry += ora_urand_key(key, 1u); }
                 const float ndc_x = rx / (float)f->width;
                 const float ndc_y = ry / (float)f->height;
                 float sx = (2.0f * ndc_x) - 1.0f;
@@ -763,7 +767,7 @@ static void render_tile(frame_ctx *f, thread_ctx *tc, int x0, int y0, int x1, in
                 const ray3 ray = mkray(sc->cam_pos, d);
                 tc->cn[ORA_C_PRIMARY] += 1;
                 hit_rec h;
-                if (accel_intersect(f->accel, &ray, 1, &h, tc->cn)) final = cadd(final, color_hit(f, tc, &h, 0));
+                if (accel_intersect(f->accel, &ray, 1, &h, tc->cn)) final = cadd(final, color_hit(f, tc, &h, 0, key));
                 else final = cadd(final, background);
             }
             final = cdiv(final, (float)f->p.spp);

@@ -118,8 +118,11 @@ int ora_render_frame(const ora_accel *a, const ora_render_params *p, float *rgb,
 /* write_ppm (io/image/ppm.hpp:7-25): returns bytes written into buf (or needed if buf==NULL). */
 size_t ora_write_ppm(const float *rgb, int width, int height, char *buf, size_t cap);
 
-/* Counter-based RNG shared by the oracle and the HIP path (replaces utils/rand.hpp:5-19). */
-float ora_urand01(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t counter);
+/* Counter-based RNG shared by the oracle and the HIP path (replaces utils/rand.hpp:5-19): keyed by the position of a
+ * ray in its sample's ray tree (see rt_oracle.c). */
+uint32_t ora_root_key(uint32_t seed, uint32_t pixel, uint32_t sample);
+uint32_t ora_child_key(uint32_t key, uint32_t child);
+float ora_urand_key(uint32_t key, uint32_t j);
 /* deterministic sin/cos used for GI directions on both sides */
 void ora_sincos(float angle, float *s, float *c);
 

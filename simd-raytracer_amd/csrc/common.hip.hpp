@@ -6,30 +6,35 @@
 namespace rtk {
 namespace dev {
 
-// Counter-based RNG: the reference's thread_local minstd_rand (utils/rand.hpp:5-19) is seeded identically on
-// every thread and handed out by a racy tile queue, so its stream cannot be reproduced.  Here a
-// draw is a pure function of (seed, absolute pixel, sample, draw index): frames do not depend on the wave/bucket/
-// rank layout.  det_sincos (kernels.hip) is a fixed double-precision sin/cos (Cody-Waite + Taylor) standing in for
-// std::sin/std::cos(float) at render.hpp:160-167: integer and IEEE-double operations only, so a CPU
-// restatement of the same formula reproduces it bit for bit.
+// Counter-based RNG.  The reference's thread_local minstd_rand (utils/rand.hpp:5-19) is seeded identically on every
+// thread and handed out by a racy tile queue, so its stream cannot be reproduced.  Here a draw is
+// keyed by the POSITION OF A RAY IN ITS SAMPLE'S RAY TREE: root key = f(seed, absolute pixel, sample); a secondary
+// ray's key derives from its parent ray's key and its child index; draw j at a ray is a pure function of (key, j).
+// Frames therefore depend neither on the wave / bucket / rank layout nor on the order in which a traversal visits
+// the tree (recursive CPU code, the per-lane state machine and the level-by-level wavefront draw the same numbers).
+// det_sincos (kernels.hip) is a fixed double-precision sin/cos (Cody-Waite + Taylor) standing in for
+// std::sin/std::cos(float) at render.hpp:160-167: integer and IEEE-double operations only.
 __device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
     const uint32_t s = x * 747796405u + 2891336453u;
     const uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
     return (w >> 22u) ^ w;
 }
-__device__ __forceinline__ float urand01(uint32_t seed_hash, uint32_t pixel, uint32_t sample, uint32_t counter) {
-    const uint32_t h = pcg_hash(counter + pcg_hash(sample + pcg_hash(pixel + seed_hash)));
+__device__ __forceinline__ uint32_t root_key(uint32_t seed_hash, uint32_t pixel, uint32_t sample) {
+    return pcg_hash(sample + pcg_hash(pixel + seed_hash));                  // seed_hash = pcg_hash(seed)
+}
+__device__ __forceinline__ uint32_t child_key(uint32_t key, uint32_t child) { return pcg_hash(key ^ (0x632BE5ABu * (child + 1u))); }
+__device__ __forceinline__ float urand_key(uint32_t key, uint32_t j) {
+    const uint32_t h = pcg_hash(key + j * 0x9E3779B9u + 0x85EBCA6Bu);
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
-// Camera ray of pixel (px, py), sample `sample` (render.hpp:35-62).  `draws` is the sample's RNG draw counter.
-__device__ __forceinline__ Ray camera_ray(const RenderArgs &A, const uint32_t px, const uint32_t py, const uint32_t pixel,
-                                          const uint32_t sample, const uint32_t seed_hash, uint32_t &draws) {
+// Camera ray of pixel (px, py) (render.hpp:35-62); `key` is the sample's root key (draws 0 and 1 jitter the sample).
+__device__ __forceinline__ Ray camera_ray(const RenderArgs &A, const uint32_t px, const uint32_t py, const uint32_t key) {
     float rx = (float)px, ry = (float)py;
     if (A.spp == 1) { rx += 0.5f; ry += 0.5f; }
     else {
-        rx += urand01(seed_hash, pixel, sample, draws++);
-        ry += urand01(seed_hash, pixel, sample, draws++);
+        rx += urand_key(key, 0u);
+        ry += urand_key(key, 1u);
     }
     const float ndc_x = rx / (float)A.width, ndc_y = ry / (float)A.height;
     float sx = (2.0f * ndc_x) - 1.0f;

@@ -119,10 +119,11 @@ enum : int { ST_NEW_SAMPLE = 0, ST_TRACE, ST_SHADE, ST_LIGHT, ST_RETURN, ST_DONE
 enum : int { PEND_CHILD_BG = 0, PEND_CHILD_BLACK = 1, PEND_SHADOW = 2 };
 enum : uint32_t { FR_REFR_A = 0, FR_REFR_B = 1, FR_DIFFUSE = 2 };
 
-struct Frame {            // 14 dwords, lives in scratch; touched only at refractive / GI events
+struct Frame {            // 15 dwords, lives in scratch; touched only at refractive / GI events
     float a[12];
     uint32_t meta;        // kind | depth << 8 | iteration << 16
     uint32_t tri;
+    uint32_t key;         // RNG key of the ray whose hit this frame shades
 };
 
 template <int MODE, bool STATS, bool FORKS, bool LDS_NODES, int SLICES, bool PRIMED = false>
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
     int state = valid ? ST_NEW_SAMPLE : ST_DONE;
     int pend = PEND_CHILD_BG;
     int sample = 0, depth = 0, light_k = 0;
-    uint32_t draws = 0, nrays = 0;
+    uint32_t rkey = 0, nrays = 0;         // rkey: RNG key of the ray in flight (position in the sample's ray tree)
     bool cull = false;
     Ray ray = make_ray(black, mk(1.f, 1.f, 1.f));
     V3 pixel_sum = black, ret = black;
@@ -202,8 +203,8 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
                     state = ST_DONE;
                     continue;
                 }
-                draws = 0;
-                ray = camera_ray(A, px, py, pixel, (uint32_t)sample, seed_hash, draws);
+                rkey = root_key(seed_hash, pixel, (uint32_t)sample);
+                ray = camera_ray(A, px, py, rkey);
                 cull = true; depth = 0; pend = PEND_CHILD_BG; fsp = 0;
                 primed = PRIMED;
                 state = ST_TRACE;
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
                     const V3 rd = din - ((2.0f * dot(din, hn)) * hn);
                     const V3 ro = P + (A.reflection_bias * rd);
                     ray = make_ray(ro, rd);
+                    rkey = child_key(rkey, 0u);
                     cull = false; depth += 1; pend = PEND_CHILD_BG;
                     state = ST_TRACE;
                 } else if (kind == RTK_MAT_REFRACTIVE) {                                        // :252-301
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
                     const V3 ro = P + (A.reflection_bias * rd);
                     if (eta_r / eta_i < sin_i_n) {                                              // total internal reflection
                         ray = make_ray(ro, rd);
+                        rkey = child_key(rkey, 0u);
                         cull = false; depth += 1; pend = PEND_CHILD_BLACK;
                         state = ST_TRACE;
                     } else {
@@ -245,8 +248,10 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
                             f.a[3] = rd.x; f.a[4] = rd.y; f.a[5] = rd.z;
                             f.a[6] = fresnel;
                             f.meta = FR_REFR_A | ((uint32_t)depth << 8);
+                            f.key = rkey;
                         }
                         ray = make_ray(P + (A.refraction_bias * r), r);
+                        rkey = child_key(rkey, 0u);
                         cull = false; depth += 1; pend = PEND_CHILD_BLACK;
                         state = ST_TRACE;
                     }
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
                         f.a[9] = 0.f; f.a[10] = 0.f; f.a[11] = 0.f;
                         f.meta = FR_DIFFUSE | ((uint32_t)depth << 8);
                         f.tri = hit_tri;
+                        f.key = rkey;
                         state = ST_RETURN;      // the frame handler below issues GI ray 0 (ret = 0 adds nothing)
                         ret = black;
                         f.meta |= 0xFFFF0000u;  // iteration = -1: "no child returned yet"
@@ -308,6 +314,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
                     f.a[7] = ret.x; f.a[8] = ret.y; f.a[9] = ret.z;
                     f.meta = FR_REFR_B | ((uint32_t)fdepth << 8);
                     ray = make_ray(mk(f.a[0], f.a[1], f.a[2]), mk(f.a[3], f.a[4], f.a[5]));
+                    rkey = child_key(f.key, 1u);
                     cull = false; depth = fdepth + 1; pend = PEND_CHILD_BLACK;
                     state = ST_TRACE;
                 } else if (kind == FR_REFR_B) {                              // :301
@@ -327,11 +334,11 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
                         const V3 right = normalized(cross(fd, fhn));
                         const V3 up = fhn;
                         const V3 fwd = cross(right, up);
-                        const float a_xy = PI_F * urand01(seed_hash, pixel, (uint32_t)sample, draws++);
+                        const float a_xy = PI_F * urand_key(f.key, 2u + 2u * (uint32_t)it);
                         float s1, c1;
                         det_sincos(a_xy, s1, c1);
                         V3 rv = mk(c1, s1, 0.0f);
-                        const float a_xz = PI_F * urand01(seed_hash, pixel, (uint32_t)sample, draws++) * 2.0f;
+                        const float a_xz = PI_F * urand_key(f.key, 3u + 2u * (uint32_t)it) * 2.0f;
                         float s2, c2;
                         det_sincos(a_xz, s2, c2);
                         rv = mk(c2 * rv.x + 0.0f * rv.y + (-s2) * rv.z, 0.0f * rv.x + 1.0f * rv.y + 0.0f * rv.z,
@@ -341,6 +348,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
                                           up.x * rv.x + up.y * rv.y + up.z * rv.z,
                                           fwd.x * rv.x + fwd.y * rv.y + fwd.z * rv.z);
                         ray = make_ray(org, dir);
+                        rkey = child_key(f.key, (uint32_t)it);
                         cull = false; depth = fdepth + 1; pend = PEND_CHILD_BLACK;
                         state = ST_TRACE;
                     } else {                                                 // GI done: light this hit
@@ -452,8 +460,7 @@ __global__ __launch_bounds__(64 * SLICES, 8) void k_primary(RenderArgs A) {
     const uint32_t ly = (sub / A.blocks_per_bucket_side) * 8u + (lane >> 3);
     const uint32_t px = bx + lx, py = by + ly;
     const bool valid = (bucket < A.n_buckets) & (lx < A.bucket) & (ly < A.bucket) & (px < A.width) & (py < A.height);
-    uint32_t draws = 0;
-    const Ray ray = camera_ray(A, px, py, py * A.width + px, 0u, pcg_hash(A.seed), draws);
+    const Ray ray = camera_ray(A, px, py, root_key(pcg_hash(A.seed), py * A.width + px, 0u));
     Stats st = {0, 0, 0, 0, 0, 0};
     const Cand c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, true, valid, st, sx);
     group_post_exit(&group_sh[0]);

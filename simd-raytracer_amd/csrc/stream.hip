@@ -130,8 +130,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
             const uint32_t px = bx + lx, py = by + ly;
             valid = (bucket < A.n_buckets) & (lx < A.bucket) & (ly < A.bucket) & (px < A.width) & (py < A.height);
             pix = (uint32_t)A.out_index(local_bucket, lx, ly, px, py);
-            uint32_t draws = 0;
-            ray = camera_ray(A, px, py, py * A.width + px, (uint32_t)S.sample, pcg_hash(A.seed), draws);
+            ray = camera_ray(A, px, py, root_key(pcg_hash(A.seed), py * A.width + px, (uint32_t)S.sample));
         } else {
             const uint32_t i = item * 64u + lane;
             valid = i < n_rays;

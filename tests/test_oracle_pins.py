@@ -140,9 +140,13 @@ def test_deterministic_sincos_is_accurate(ora):
     assert np.max(np.abs(got - ref)) < 1.2e-7
 
 
-def test_urand01_is_uniform_and_keyed(ora):
-    v = np.array([ora.urand01(42, p, s, c) for p in range(40) for s in range(5) for c in range(5)])
+def test_rng_is_uniform_and_keyed_by_tree_position(ora):
+    keys = [ora.root_key(42, p, s) for p in range(60) for s in range(4)]
+    v = np.array([ora.urand_key(k, j) for k in keys for j in range(6)])
     assert v.min() >= 0.0 and v.max() < 1.0
     assert abs(v.mean() - 0.5) < 0.03
     assert len(np.unique(v)) > 0.99 * len(v)
-    assert ora.urand01(42, 7, 1, 3) == ora.urand01(42, 7, 1, 3) != ora.urand01(43, 7, 1, 3)
+    assert ora.root_key(42, 7, 1) == ora.root_key(42, 7, 1) != ora.root_key(43, 7, 1)
+    k = ora.root_key(42, 7, 1)
+    kids = {ora.child_key(k, c) for c in range(8)} | {ora.child_key(ora.child_key(k, 0), c) for c in range(8)}
+    assert len(kids) == 16 and k not in kids
