@@ -60,8 +60,8 @@ struct rtk_accel {
     rtk::DevLight *d_lights = nullptr;
     unsigned long long *d_counters = nullptr;     // 8 x u64 in rtk_counters order + kRayCounterShards ray-count shards
     // streaming-pipeline workspace (grown on demand)
-    rtk::dev::StreamWs ws = {{nullptr, nullptr}, nullptr, nullptr, nullptr, nullptr};
-    size_t ws_pixels = 0, ws_lights = 0;
+    rtk::dev::StreamWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    size_t ws_pixels = 0, ws_lights = 0, ws_nodes = 0;
     bool ws_sum = false;
     // two-pass workspace
     float4 *tp_prim = nullptr;
@@ -115,24 +115,28 @@ dev::TreeView tree_view(const rtk_accel *a) {
 
 // (Re)allocates the streaming workspace for `pixels` output pixels.  Allocation synchronises the device, so it only
 // happens when a larger frame (or more lights / multi-sample) is requested than ever before on this accel.
-int ensure_stream_ws(rtk_accel *a, size_t pixels, size_t lights, bool need_sum) {
+int ensure_stream_ws(rtk_accel *a, size_t pixels, size_t nodes, size_t lights, bool need_sum) {
     if (lights == 0) lights = 1;
-    if (pixels <= a->ws_pixels && lights <= a->ws_lights && (!need_sum || a->ws_sum)) return RTK_OK;
+    if (pixels <= a->ws_pixels && nodes <= a->ws_nodes && lights <= a->ws_lights && (!need_sum || a->ws_sum)) return RTK_OK;
     const size_t np = pixels > a->ws_pixels ? pixels : a->ws_pixels;
+    const size_t nn = nodes > a->ws_nodes ? nodes : a->ws_nodes;
     const size_t nl = lights > a->ws_lights ? lights : a->ws_lights;
     const bool sum = need_sum || a->ws_sum;
+    if (nn > 0xFFFFFFF0ull) return fail(RTK_ERR_INVALID, "frame too large for the streaming pipeline's 32-bit node ids");
     RTK_HIP(hipDeviceSynchronize());
-    (void)hipFree(a->ws.path[0]); (void)hipFree(a->ws.path[1]); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
+    (void)hipFree(a->ws.rays); (void)hipFree(a->ws.nodes); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
     (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
-    a->ws = dev::StreamWs{{nullptr, nullptr}, nullptr, nullptr, nullptr, nullptr};
-    a->ws_pixels = 0; a->ws_lights = 0; a->ws_sum = false;
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.path[0]), np * sizeof(dev::PathRay)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.path[1]), np * sizeof(dev::PathRay)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.hits), np * sizeof(dev::HitRec)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.contrib), np * nl * sizeof(float2)));
+    a->ws = dev::StreamWs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    a->ws_pixels = 0; a->ws_nodes = 0; a->ws_lights = 0; a->ws_sum = false;
+    const size_t nh = nn / 2 + 64;                            // every shading point belongs to a distinct node
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.rays), nn * sizeof(dev::RayRec)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.nodes), nn * sizeof(dev::NodeRes)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.hits), nh * sizeof(dev::HitRec)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.contrib), nh * nl * sizeof(float2)));
     if (sum) RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.sumbuf), np * 3 * sizeof(float)));
     RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.ctrl), dev::kCtrlWords * sizeof(uint32_t)));
-    a->ws_pixels = np; a->ws_lights = nl; a->ws_sum = sum;
+    a->ws.node_cap = uint32_t(nn); a->ws.hit_cap = uint32_t(nh);
+    a->ws_pixels = np; a->ws_nodes = nn; a->ws_lights = nl; a->ws_sum = sum;
     return RTK_OK;
 }
 
@@ -346,7 +350,7 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipSetDevice(a->device);
         (void)hipFree(a->d_nodes); (void)hipFree(a->d_tris); (void)hipFree(a->d_tri_ids); (void)hipFree(a->d_shade);
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
-        (void)hipFree(a->ws.path[0]); (void)hipFree(a->ws.path[1]); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
+        (void)hipFree(a->ws.rays); (void)hipFree(a->ws.nodes); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
         (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
         (void)hipFree(a->tp_prim); (void)hipFree(a->tp_bins); (void)hipFree(a->tp_bin_list); (void)hipFree(a->tp_order);
     }
@@ -461,9 +465,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         RTK_HIP(hipMemsetAsync(d_out, 0, nf * sizeof(float), s));
     }
     // fork-free scenes (no refraction, no GI) can be rendered by the streaming pipeline (stream.hip)
-    const bool stream = !forks && p->trace_mode == RTK_TRACE_STREAM;
-    if (p->trace_mode == RTK_TRACE_STREAM && forks)
-        return fail(RTK_ERR_UNSUPPORTED, "RTK_TRACE_STREAM needs a scene without refractive materials and diffuse_rays == 0");
+    const bool stream = p->trace_mode == RTK_TRACE_STREAM;
     const bool twopass = p->trace_mode == RTK_TRACE_TWOPASS;
     if (twopass && p->spp != 1) return fail(RTK_ERR_UNSUPPORTED, "RTK_TRACE_TWOPASS needs spp == 1");
     if (twopass) {
@@ -477,31 +479,39 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         if (et != hipSuccess) return hip_fail(et, "launch two-pass frame");
     } else if (stream) {
         const size_t out_pixels = (g.world > 1) ? size_t(g.buckets_per_rank) * g.bucket * g.bucket : size_t(g.width) * g.height;
-        rc = ensure_stream_ws(a, out_pixels, a->scene.lights.size(), p->spp > 1);
+        const size_t n_root = size_t(g.buckets_per_rank) * g.blocks_side * g.blocks_side * 64;
+        // Ray-tree nodes per sample: the camera rays plus room for the secondary rays.  Refractive scenes fork (two
+        // children per interface), so they get more head room; an overflow is caught on the device and the frame
+        // redone by the megakernel.
+        size_t factor = forks ? 8 : 3;
+        if (const char *e = std::getenv("RTK_STREAM_NODE_FACTOR")) { const int v = std::atoi(e); if (v >= 1) factor = size_t(v); }
+        rc = ensure_stream_ws(a, out_pixels, n_root * factor + 4096, a->scene.lights.size(), p->spp > 1);
         if (rc != RTK_OK) return rc;
         dev::StreamArgs S;
-        S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0; S.auto_min_lanes = 12;
-        int slices = 4;
-        if (const char *e = std::getenv("RTK_STREAM_SLICES")) slices = std::atoi(e) > 1 ? 4 : 1;
+        S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root);
+        RTK_HIP(hipMemsetAsync(a->ws.ctrl, 0, dev::kCtrlWords * sizeof(uint32_t), s));
         for (int sample = 0; sample < p->spp; ++sample) {
             S.sample = sample;
-            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, slices, s);
+            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, s);
             if (es != hipSuccess) return hip_fail(es, "launch streaming pipeline");
         }
-#ifdef RTK_DEBUG_WAVE_TIME
-        {
+        // safety net: if any queue overflowed, the megakernel renders the frame again (a no-op otherwise)
+        hipError_t ef = launch_stream_overflow_reset(S, s);
+        if (ef != hipSuccess) return hip_fail(ef, "launch overflow reset");
+        dev::RenderArgs F = A;
+        F.only_if = a->ws.ctrl + dev::kCtrlOverflow;
+        ef = launch_render(F, RTK_TRACE_GROUP4, p->collect_stats != 0, forks, s);
+        if (ef != hipSuccess) return hip_fail(ef, "launch fallback k_render");
+        if (std::getenv("RTK_STREAM_DEBUG")) {
             uint32_t h[dev::kCtrlWords];
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h, a->ws.ctrl, sizeof(h), hipMemcpyDeviceToHost);
-            const char *names[3] = {"path0", "path", "shadow"};
-            for (int st = 0; st < 3; ++st) for (int lv = 0; lv < 4; ++lv) {
-                const uint32_t *d = h + dev::kCtrlDebug + (st * 4 + lv) * 4;
-                if (d[2]) std::fprintf(stderr, "[dbg] %s level %d: units %u mean %.1f us max %.1f us, longest block %.1f us (queue path %u hits %u)\n",
-                                       names[st], lv, d[2], d[0] / 100.0 / d[2], d[1] / 100.0, d[3] / 100.0,
-                                       h[dev::kCtrlPathCount + lv], h[dev::kCtrlHitCount + lv]);
-            }
+            std::fprintf(stderr, "[rtk stream] node_cap %u hit_cap %u overflow %u; nodes per level:", a->ws.node_cap, a->ws.hit_cap, h[dev::kCtrlOverflow]);
+            for (int l = 0; l <= p->max_ray_depth + 1; ++l) std::fprintf(stderr, " %u", l == 0 ? unsigned(n_root) : h[dev::kCtrlNodeCount + l]);
+            std::fprintf(stderr, "; hits:");
+            for (int l = 0; l <= p->max_ray_depth; ++l) std::fprintf(stderr, " %u", h[dev::kCtrlHitCount + l]);
+            std::fprintf(stderr, "\n");
         }
-#endif
     } else {
         // RTK_TRACE_AUTO for frames: workgroup-cooperative leaves (fastest megakernel variant on every config scene)
         const hipError_t e = launch_render(A, p->trace_mode == RTK_TRACE_AUTO ? RTK_TRACE_GROUP4 : p->trace_mode,

@@ -12,7 +12,7 @@ namespace dev {
 // ray's key derives from its parent ray's key and its child index; draw j at a ray is a pure function of (key, j).
 // Frames therefore depend neither on the wave / bucket / rank layout nor on the order in which a traversal visits
 // the tree (recursive CPU code, the per-lane state machine and the level-by-level wavefront draw the same numbers).
-// det_sincos (kernels.hip) is a fixed double-precision sin/cos (Cody-Waite + Taylor) standing in for
+// det_sincos is a fixed double-precision sin/cos (Cody-Waite + Taylor) standing in for
 // std::sin/std::cos(float) at render.hpp:160-167: integer and IEEE-double operations only.
 __device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
     const uint32_t s = x * 747796405u + 2891336453u;
@@ -26,6 +26,42 @@ __device__ __forceinline__ uint32_t child_key(uint32_t key, uint32_t child) { re
 __device__ __forceinline__ float urand_key(uint32_t key, uint32_t j) {
     const uint32_t h = pcg_hash(key + j * 0x9E3779B9u + 0x85EBCA6Bu);
     return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+static __device__ __noinline__ void det_sincos(float angle, float &s, float &c) {
+    const double x = (double)angle;
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632673412561417e+00, pio2_lo = 6.07710050650619224932e-11;
+    const double kf = __builtin_floor(x * two_over_pi + 0.5);
+    const double r = (x - kf * pio2_hi) - kf * pio2_lo;
+    const double r2 = r * r;
+    double ps = -1.0 / 1307674368000.0;
+    ps = ps * r2 + 1.0 / 6227020800.0;
+    ps = ps * r2 - 1.0 / 39916800.0;
+    ps = ps * r2 + 1.0 / 362880.0;
+    ps = ps * r2 - 1.0 / 5040.0;
+    ps = ps * r2 + 1.0 / 120.0;
+    ps = ps * r2 - 1.0 / 6.0;
+    const double sr = r + r * (r2 * ps);
+    double pc = 1.0 / 20922789888000.0;
+    pc = pc * r2 - 1.0 / 87178291200.0;
+    pc = pc * r2 + 1.0 / 479001600.0;
+    pc = pc * r2 - 1.0 / 3628800.0;
+    pc = pc * r2 + 1.0 / 40320.0;
+    pc = pc * r2 - 1.0 / 720.0;
+    pc = pc * r2 + 1.0 / 24.0;
+    pc = pc * r2 - 0.5;
+    const double cr = 1.0 + r2 * pc;
+    const long long k = (long long)kf;
+    double sv, cv;
+    switch ((int)(k & 3)) {
+        case 0: sv = sr; cv = cr; break;
+        case 1: sv = cr; cv = -sr; break;
+        case 2: sv = -sr; cv = -cr; break;
+        default: sv = -cr; cv = sr; break;
+    }
+    s = (float)sv;
+    c = (float)cv;
 }
 
 // Camera ray of pixel (px, py) (render.hpp:35-62); `key` is the sample's root key (draws 0 and 1 jitter the sample).

@@ -72,42 +72,6 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__device__ __noinline__ void det_sincos(float angle, float &s, float &c) {
-    const double x = (double)angle;
-    const double two_over_pi = 0.63661977236758134308;
-    const double pio2_hi = 1.57079632673412561417e+00, pio2_lo = 6.07710050650619224932e-11;
-    const double kf = __builtin_floor(x * two_over_pi + 0.5);
-    const double r = (x - kf * pio2_hi) - kf * pio2_lo;
-    const double r2 = r * r;
-    double ps = -1.0 / 1307674368000.0;
-    ps = ps * r2 + 1.0 / 6227020800.0;
-    ps = ps * r2 - 1.0 / 39916800.0;
-    ps = ps * r2 + 1.0 / 362880.0;
-    ps = ps * r2 - 1.0 / 5040.0;
-    ps = ps * r2 + 1.0 / 120.0;
-    ps = ps * r2 - 1.0 / 6.0;
-    const double sr = r + r * (r2 * ps);
-    double pc = 1.0 / 20922789888000.0;
-    pc = pc * r2 - 1.0 / 87178291200.0;
-    pc = pc * r2 + 1.0 / 479001600.0;
-    pc = pc * r2 - 1.0 / 3628800.0;
-    pc = pc * r2 + 1.0 / 40320.0;
-    pc = pc * r2 - 1.0 / 720.0;
-    pc = pc * r2 + 1.0 / 24.0;
-    pc = pc * r2 - 0.5;
-    const double cr = 1.0 + r2 * pc;
-    const long long k = (long long)kf;
-    double sv, cv;
-    switch ((int)(k & 3)) {
-        case 0: sv = sr; cv = cr; break;
-        case 1: sv = cr; cv = -sr; break;
-        case 2: sv = -sr; cv = -cr; break;
-        default: sv = -cr; cv = sr; break;
-    }
-    s = (float)sv;
-    c = (float)cv;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Device-side render loop.  One lane = one pixel; a wave = an 8x8 pixel block of a bucket, buckets are
 // dealt to ranks round-robin (bucket i -> rank i % world).  color_hit's recursion (render.hpp:133-308) is
@@ -131,6 +95,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : 4
     // PRIMED (second pass of a two-pass frame): pixel blocks come from tile_order (most expensive first) and the
     // camera ray's hit is read from A.prim instead of being traced again
     if (PRIMED && blockIdx.x >= *A.n_listed) return;
+    if (A.only_if != nullptr && *A.only_if == 0u) return;        // fallback launch behind the streaming pipeline: nothing overflowed
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
     // the per-lane path reads nodes from LDS; the wave-cooperative paths fetch them with scalar loads instead

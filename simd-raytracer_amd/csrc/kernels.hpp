@@ -60,6 +60,7 @@ struct RenderArgs {
     uint32_t *tile_order;             // [tile_cap] pixel blocks with work, most expensive first
     uint32_t *n_listed;               // number of entries in tile_order
     uint32_t tile_cap;
+    const uint32_t *only_if;          // non-null: the kernel does nothing unless this word is non-zero (overflow fallback)
 
     __device__ __forceinline__ size_t out_index(uint32_t local_bucket, uint32_t lx, uint32_t ly, uint32_t px,
                                                 uint32_t py) const {

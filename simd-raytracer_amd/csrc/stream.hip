@@ -1,19 +1,25 @@
-// Streaming ("wavefront") frame pipeline for fork-free scenes (no refractive material, no diffuse GI rays).
+// Streaming ("wavefront") frame pipeline: color_hit's recursion (render/render.hpp:133-308) evaluated level by level.
 //
-// In such scenes color_hit (render/render.hpp:133-308) never forks: a pixel's colour is the colour of the last
-// surface of its reflection chain (reflective = tail call, :239-250), i.e. a background / constant colour or ONE
-// diffuse light sum (:184-208).  The recursion therefore unrolls into per-depth batches:
+// The megakernel (kernels.hip) walks each pixel's ray tree depth-first inside one lane: a pixel behind a refractive
+// object needs hundreds of dependent traces while the other lanes of its wave idle.  Here every ray of a sample's
+// ray tree is a NODE (stream.hpp) and all nodes of one depth are traced together:
 //
-//   k_path(d)    closest hit for every path ray of depth d (camera rays at d = 0) + material switch; reflective hits
-//                append a path ray for depth d+1, diffuse hits append a shading point, everything else writes its
-//                pixel.  Appends are compacted with wave ballot / mbcnt prefix and one atomic per wave and queue.
-//   k_shadow(d)  one closest-hit shadow query per (shading point, light), is_occluded semantics (:110-131)
-//   k_resolve(d) sums the unoccluded lights IN LIGHT ORDER (float addition is not associative) and writes the pixel
+//   k_path(d)     closest hit for every depth-d ray (camera rays at d = 0) + material switch.  Leaves get their
+//                 value at once; reflective / refractive / diffuse-GI hits append their child rays as depth d+1
+//                 nodes (compacted with a wave prefix sum and one atomic per wave); diffuse hits also append a
+//                 shading point.
+//   k_shadow(d)   one is_occluded query (render.hpp:110-131, stepping through transmissive surfaces) per
+//                 (shading point, light)
+//   k_combine(d)  bottom-up, d = max_depth-1 .. 0: inner nodes compute their value from their children in exactly the
+//                 order the recursion uses (GI children first, then the lights in order, then the division; fresnel
+//                 blend of the reflection and refraction child), so the floats equal the recursive evaluation bit
+//                 for bit; depth 0 writes the pixels.
 //
-// Every kernel carries one ray and one candidate per lane and nothing else, so eight waves fit on a SIMD and
-// scalar-load latency is hidden by occupancy instead of by helper waves; the work of a heavy pixel block is spread
-// over several short waves instead of one long one.  Results are bit-identical to the megakernel (same device
-// functions, same operation order).
+// Random numbers are keyed by tree position (common.hip.hpp), so the breadth-first order changes nothing.
+// The trace kernels carry one ray + one candidate per lane (8 waves per SIMD), work units are drawn from atomic
+// tickets, and a unit of 64 rays is served by an owner wave plus helper waves that split large leaves
+// (trace.hip.hpp).  If a queue overflows its preallocated capacity (deep forks in an adversarial scene) the frame is
+// redone by the megakernel — slower, never wrong.
 #include <hip/hip_runtime.h>
 
 #include "common.hip.hpp"
@@ -28,23 +34,61 @@ __device__ __forceinline__ uint32_t lane_prefix(const unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// wave-compacted append: returns this lane's slot (only meaningful where `want`)
-__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, const bool want) {
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
-    if (mask == 0ull) return 0u;
-    uint32_t base = 0u;
-    if (__lane_id() == 0u) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    return base + lane_prefix(mask);
+// Wave-compacted append of `n` records per lane (n may differ per lane): returns the lane's first slot relative to
+// the queue's start, or 0xFFFFFFFF for every lane when the wave's records do not fit below `cap`.
+__device__ __forceinline__ uint32_t wave_append_n(uint32_t *counter, const uint32_t n, const uint32_t base, const uint32_t cap,
+                                                  uint32_t *overflow) {
+    const uint32_t lane = __lane_id();
+    uint32_t incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += t;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total == 0u) return 0u;
+    uint32_t start = 0u;
+    if (lane == 0u) start = atomicAdd(counter, total);
+    start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+    if (base + start + total > cap) {
+        if (lane == 0u) atomicExch(overflow, 1u);
+        return 0xFFFFFFFFu;
+    }
+    return start + (incl - n);
 }
 
-// Dynamic work distribution for the queue-driven (persistent) stages: a unit's first item is its own index, every
-// further item is drawn from an atomic ticket, so units that got cheap items simply come back for more and the
-// stage ends when the queue is empty instead of when the unluckiest static share is done.
+__device__ __forceinline__ uint32_t wave_append_1(uint32_t *counter, const bool want, const uint32_t base, const uint32_t cap,
+                                                  uint32_t *overflow) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
+    if (mask == 0ull) return 0u;
+    uint32_t start = 0u;
+    if (__lane_id() == 0u) start = atomicAdd(counter, (uint32_t)__popcll(mask));
+    start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+    if (base + start + (uint32_t)__popcll(mask) > cap) {
+        if (__lane_id() == 0u) atomicExch(overflow, 1u);
+        return 0xFFFFFFFFu;
+    }
+    return start + lane_prefix(mask);
+}
+
+// Dynamic work distribution for the queue-driven stages: a unit's first item is its own index, every further item
+// is drawn from an atomic ticket, so the stage ends when the queue is empty rather than when the unluckiest static
+// share is done.
 __device__ __forceinline__ uint32_t next_item(uint32_t *ticket, const uint32_t n_units) {
     uint32_t t = 0u;
     if (__lane_id() == 0u) t = atomicAdd(ticket, 1u);
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + n_units;
+}
+
+// first node id and node count of depth level `level`
+__device__ __forceinline__ void level_range(const uint32_t *count_words, const uint32_t level0_count, const uint32_t level,
+                                            const uint32_t cap, uint32_t &base, uint32_t &count) {
+    unsigned long long b = 0ull;
+    for (uint32_t j = 0; j < level; ++j) b += (j == 0u) ? level0_count : count_words[j];
+    const unsigned long long c = (level == 0u) ? level0_count : count_words[level];
+    // a counter that ran past the capacity (overflow) must never turn into an out-of-bounds node id
+    base = b < cap ? (uint32_t)b : cap;
+    count = (b + c <= cap) ? (uint32_t)c : cap - base;
 }
 
 // final_color += colour ; after the last sample: pixels[y][x] = final_color / spp   (render.hpp:66-74)
@@ -81,11 +125,19 @@ __device__ __forceinline__ void add_rays(const StreamArgs &S, const Stats &st, c
     if (__lane_id() == 0u && total != 0u) atomicAdd(c + 8 + (shard % (uint32_t)kRayCounterShards), (unsigned long long)total);
 }
 
+__device__ __forceinline__ void store_ray(RayRec *dst, const V3 o, const V3 d, const uint32_t parent, const uint32_t pixel,
+                                          const uint32_t key, const uint32_t info) {
+    float4 *q = reinterpret_cast<float4 *>(dst);
+    q[0] = make_float4(o.x, o.y, o.z, __uint_as_float(parent));
+    q[1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
+    q[2] = make_float4(__uint_as_float(key), __uint_as_float(info), 0.f, 0.f);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// k_path: LEVEL0 = camera rays, one wave per 8x8 pixel block (same bucket / rank mapping as k_render);
-// otherwise depth-`level` reflection rays from the queue, waves striding over groups of 64 rays.
+// k_path: LEVEL0 = camera rays, one work unit per 8x8 pixel block (same bucket / rank mapping as k_render);
+// otherwise the depth-`level` nodes, units of 64 consecutive nodes drawn from a ticket.
 template <bool LEVEL0, bool STATS, int SLICES>
 __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     const RenderArgs &A = S.r;
@@ -97,118 +149,151 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
         return;
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gwave = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;    // work-unit id
-    const uint32_t n_waves = SLICES > 1 ? gridDim.x : gridDim.x * (blockDim.x >> 6);
+    const uint32_t gunit = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    const uint32_t n_units_grid = SLICES > 1 ? gridDim.x : gridDim.x * (blockDim.x >> 6);
     const V3 background = mk(A.background[0], A.background[1], A.background[2]);
+    const V3 black = mk(0.f, 0.f, 0.f);
+    const float PI_F = 3.14159265358979323846f;
     const uint32_t level = S.level;
-    const uint32_t n_rays = LEVEL0 ? 0u : S.ws.ctrl[kCtrlPathCount + level];
-    const uint32_t n_items = LEVEL0 ? 1u : (n_rays + 63u) >> 6;
-    const PathRay *qin = S.ws.path[level & 1u];
-    PathRay *qout = S.ws.path[(level + 1u) & 1u];
+    uint32_t *ctrl = S.ws.ctrl;
+    if (ctrl[kCtrlOverflow] != 0u) {                                           // a queue overflowed: the megakernel redoes the frame
+        if (SLICES > 1) group_post_exit(&group_sh[0]);
+        return;
+    }
+    uint32_t base, count;
+    level_range(ctrl + kCtrlNodeCount, S.n_root, level, S.ws.node_cap, base, count);
+    const uint32_t next_base = base + count;                                  // where depth level+1 starts
+    uint32_t hit_base = 0u;
+    for (uint32_t j = 0; j < level; ++j) hit_base += ctrl[kCtrlHitCount + j];
+    const uint32_t n_items = (count + 63u) >> 6;
     Stats st = {0, 0, 0, 0, 0, 0};
     SliceCtx sx = {SLICES > 1 ? &group_sh[0] : nullptr, A.slice_min_tris, 0u, true, 0u};
     uint32_t nrays = 0;
 
-#ifdef RTK_DEBUG_WAVE_TIME
-    const unsigned long long dbg_b0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    for (uint32_t item = LEVEL0 ? 0u : gwave; item < n_items;
-         item = LEVEL0 ? n_items : next_item(S.ws.ctrl + kCtrlTicket + level, n_waves)) {
-#ifdef RTK_DEBUG_WAVE_TIME
-        const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
-        bool valid;
-        uint32_t pix = 0;
+    for (uint32_t item = gunit; item < n_items; item = LEVEL0 ? n_items : next_item(ctrl + kCtrlTicket + level, n_units_grid)) {
+        const uint32_t node = base + item * 64u + lane;
+        const bool in_range = item * 64u + lane < count;
+        bool valid = in_range;
+        uint32_t pix = 0xFFFFFFFFu, key = 0u;
+        bool miss_bg = true;
         Ray ray;
         if (LEVEL0) {
             const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
-            const uint32_t local_bucket = gwave / bpb, sub = gwave % bpb;
+            const uint32_t local_bucket = item / bpb, sub = item % bpb;
             const uint32_t bucket = (uint32_t)A.rank + local_bucket * (uint32_t)A.world;
             const uint32_t bx = (bucket % A.tiles_x) * A.bucket, by = (bucket / A.tiles_x) * A.bucket;
             const uint32_t lx = (sub % A.blocks_per_bucket_side) * 8u + (lane & 7u);
             const uint32_t ly = (sub / A.blocks_per_bucket_side) * 8u + (lane >> 3);
             const uint32_t px = bx + lx, py = by + ly;
-            valid = (bucket < A.n_buckets) & (lx < A.bucket) & (ly < A.bucket) & (px < A.width) & (py < A.height);
-            pix = (uint32_t)A.out_index(local_bucket, lx, ly, px, py);
-            ray = camera_ray(A, px, py, root_key(pcg_hash(A.seed), py * A.width + px, (uint32_t)S.sample));
+            valid = valid & (bucket < A.n_buckets) & (lx < A.bucket) & (ly < A.bucket) & (px < A.width) & (py < A.height);
+            if (valid) pix = (uint32_t)A.out_index(local_bucket, lx, ly, px, py);
+            key = root_key(pcg_hash(A.seed), py * A.width + px, (uint32_t)S.sample);
+            ray = camera_ray(A, px, py, key);
         } else {
-            const uint32_t i = item * 64u + lane;
-            valid = i < n_rays;
-            const float4 *q = reinterpret_cast<const float4 *>(qin + (valid ? i : 0u));
-            const float4 a = q[0], b = q[1];
-            pix = __float_as_uint(a.w);
+            const float4 *q = reinterpret_cast<const float4 *>(S.ws.rays + (in_range ? node : base));
+            const float4 a = q[0], b = q[1], c = q[2];
+            pix = __float_as_uint(b.w);
+            key = __float_as_uint(c.x);
+            const uint32_t info = __float_as_uint(c.y);
+            valid = valid & ((info & kRayValid) != 0u);
+            miss_bg = (info & kRayMissBackground) != 0u;
             ray = make_ray(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z));
         }
-        Cand c;
-        c.t = kFltMax; c.u = c.v = 0.f; c.k = kMiss;
-        c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, LEVEL0, valid, st, sx);
+        const Cand c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, LEVEL0, valid, st, sx);
         nrays += valid ? 1u : 0u;
 
-        // ---- material switch (color_hit, render.hpp:133-308, fork-free subset)
-        bool write = false, push_path = false, push_hit = false;
-        V3 ret = background, P = background, n_or_d = background, o_next = background;
-        uint32_t mat = 0;
+        // ---- color_hit's material switch (render.hpp:133-308): node kind + the rays it spawns
+        uint32_t kind = NODE_LEAF, nchild = 0u, aux = 0u, mat = 0u;
+        V3 value = black, P = black, hn = black, ncos = black;
+        V3 c0o = black, c0d = black, c1o = black, c1d = black;                  // explicit children (reflect / refract)
+        bool c0_bg = false, push_hit = false;
         if (valid) {
-            if (c.k == kMiss) { write = true; ret = background; }                       // camera miss / reflective miss: background
-            else if ((int)level == A.max_depth) { write = true; ret = background; }     // render.hpp:138-139
+            if (c.k == kMiss) value = miss_bg ? background : black;
+            else if ((int)level == A.max_depth) value = background;                            // render.hpp:138-139
             else {
                 const Surface s = reconstruct(A.tree, c);
                 P = ray.o + (c.t * ray.d);
+                hn = s.hit_normal;
                 mat = s.material;
                 const DevMaterial *m = A.materials + mat;
-                const int kind = m->kind;
-                if (kind == RTK_MAT_CONSTANT) { write = true; ret = mk(m->albedo[0], m->albedo[1], m->albedo[2]); }
-                else if (kind == RTK_MAT_REFLECTIVE) {                                   // render.hpp:239-250
-                    const V3 rd = ray.d - ((2.0f * dot(ray.d, s.hit_normal)) * s.hit_normal);
-                    o_next = P + (A.reflection_bias * rd);
-                    n_or_d = rd;
-                    push_path = true;
-                } else {                                                                 // diffuse: light loop comes later
-                    n_or_d = m->smooth ? s.hit_normal : s.face_normal;
-                    push_hit = true;
+                const int mkind = m->kind;
+                if (mkind == RTK_MAT_CONSTANT) value = mk(m->albedo[0], m->albedo[1], m->albedo[2]);
+                else if (mkind == RTK_MAT_REFLECTIVE) {                                         // :239-250
+                    c0d = ray.d - ((2.0f * dot(ray.d, hn)) * hn);
+                    c0o = P + (A.reflection_bias * c0d);
+                    c0_bg = true; kind = NODE_PASS; nchild = 1u;
+                } else if (mkind == RTK_MAT_REFRACTIVE) {                                       // :252-301
+                    V3 n = normalized(m->smooth ? hn : s.face_normal);
+                    const V3 i = normalized(ray.d);
+                    float eta_i = 1.0f, eta_r = m->ior;
+                    if (0.0f < dot(i, n)) { const float tmp = eta_i; eta_i = eta_r; eta_r = tmp; n = neg(n); }
+                    const float cos_i_n = -dot(i, n);
+                    const float sin_i_n = __builtin_sqrtf(1.0f - cos_i_n * cos_i_n);
+                    const V3 rd = i - ((2.0f * dot(i, n)) * n);
+                    const V3 ro = P + (A.reflection_bias * rd);
+                    if (eta_r / eta_i < sin_i_n) {                                              // total internal reflection
+                        c0o = ro; c0d = rd; kind = NODE_PASS; nchild = 1u;
+                    } else {
+                        const float sin_r = ((sin_i_n * eta_i) / eta_r);
+                        const float cos_r = __builtin_sqrtf(1.0f - sin_r * sin_r);
+                        const V3 r = (cos_r * neg(n)) + (sin_r * normalized(i + (cos_i_n * n)));
+                        const double x = (double)(1.0f + dot(i, n));                           // :300, x^5 in double
+                        aux = __float_as_uint((float)(0.5 * (x * x * x * x * x)));
+                        c0o = P + (A.refraction_bias * r); c0d = r;                             // child 0: refraction
+                        c1o = ro; c1d = rd;                                                     // child 1: reflection
+                        kind = NODE_REFR; nchild = 2u;
+                    }
+                } else {                                                                        // diffuse, :148-209
+                    ncos = m->smooth ? hn : s.face_normal;
+                    kind = NODE_DIFF; nchild = (uint32_t)A.diffuse_rays; push_hit = true;
                 }
             }
         }
-        if (write) emit_pixel(S, pix, ret);
-        {
-            const uint32_t slot = wave_append(S.ws.ctrl + kCtrlPathCount + level + 1u, push_path);
-            if (push_path) {
-                float4 *q = reinterpret_cast<float4 *>(qout + slot);
-                q[0] = make_float4(o_next.x, o_next.y, o_next.z, __uint_as_float(pix));
-                q[1] = make_float4(n_or_d.x, n_or_d.y, n_or_d.z, 0.f);
+        // ---- append the children (depth level+1 nodes) and the shading point
+        uint32_t child_slot = wave_append_n(ctrl + kCtrlNodeCount + level + 1u, nchild, next_base, S.ws.node_cap, ctrl + kCtrlOverflow);
+        const uint32_t hit_slot = wave_append_1(ctrl + kCtrlHitCount + level, push_hit, hit_base, S.ws.hit_cap, ctrl + kCtrlOverflow);
+        if (child_slot == 0xFFFFFFFFu || hit_slot == 0xFFFFFFFFu) { kind = NODE_LEAF; nchild = 0u; push_hit = false; child_slot = 0u; }
+        const uint32_t first_child = next_base + child_slot;
+        if (kind == NODE_PASS || kind == NODE_REFR) {
+            store_ray(S.ws.rays + first_child, c0o, c0d, node, pix, child_key(key, 0u), kRayValid | (c0_bg ? kRayMissBackground : 0u));
+            if (kind == NODE_REFR) store_ray(S.ws.rays + first_child + 1u, c1o, c1d, node, pix, child_key(key, 1u), kRayValid);
+        } else if (kind == NODE_DIFF) {
+            aux = hit_base + hit_slot;
+            float4 *q = reinterpret_cast<float4 *>(S.ws.hits + aux);
+            q[0] = make_float4(P.x, P.y, P.z, __uint_as_float(node));
+            q[1] = make_float4(ncos.x, ncos.y, ncos.z, __uint_as_float(mat));
+            for (uint32_t gi = 0; gi < nchild; ++gi) {                                          // GI rays, :151-176
+                const V3 right = normalized(cross(ray.d, hn));
+                const V3 up = hn;
+                const V3 fwd = cross(right, up);
+                float s1, c1, s2, c2;
+                det_sincos(PI_F * urand_key(key, 2u + 2u * gi), s1, c1);
+                V3 rv = mk(c1, s1, 0.0f);
+                det_sincos(PI_F * urand_key(key, 3u + 2u * gi) * 2.0f, s2, c2);
+                rv = mk(c2 * rv.x + 0.0f * rv.y + (-s2) * rv.z, 0.0f * rv.x + 1.0f * rv.y + 0.0f * rv.z,
+                        s2 * rv.x + 0.0f * rv.y + c2 * rv.z);
+                const V3 org = P + (A.reflection_bias * hn);
+                const V3 dir = mk(right.x * rv.x + right.y * rv.y + right.z * rv.z, up.x * rv.x + up.y * rv.y + up.z * rv.z,
+                                  fwd.x * rv.x + fwd.y * rv.y + fwd.z * rv.z);
+                store_ray(S.ws.rays + first_child + gi, org, dir, node, pix, child_key(key, gi), kRayValid);
             }
         }
-        {
-            const uint32_t slot = wave_append(S.ws.ctrl + kCtrlHitCount + level, push_hit);
-            if (push_hit) {
-                float4 *q = reinterpret_cast<float4 *>(S.ws.hits + slot);
-                q[0] = make_float4(P.x, P.y, P.z, __uint_as_float(pix));
-                q[1] = make_float4(n_or_d.x, n_or_d.y, n_or_d.z, __uint_as_float(mat));
-            }
+        if (in_range) {
+            float4 *q = reinterpret_cast<float4 *>(S.ws.nodes + node);
+            q[0] = make_float4(value.x, value.y, value.z, __uint_as_float(kind));
+            q[1] = make_float4(__uint_as_float(first_child), __uint_as_float(aux), __uint_as_float(nchild), __uint_as_float(pix));
         }
-#ifdef RTK_DEBUG_WAVE_TIME
-        if (lane == 0u && level < 4u) {
-            const uint32_t dt = (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_t0);
-            uint32_t *d = S.ws.ctrl + kCtrlDebug + ((LEVEL0 ? 0u : 1u) * 4u + level) * 4u;
-            atomicAdd(d + 0, dt); atomicMax(d + 1, dt); atomicAdd(d + 2, 1u);
-        }
-#endif
     }
-#ifdef RTK_DEBUG_WAVE_TIME
-    if (lane == 0u && level < 4u)
-        atomicMax(S.ws.ctrl + kCtrlDebug + ((LEVEL0 ? 0u : 1u) * 4u + level) * 4u + 3, (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_b0));
-#endif
     if (SLICES > 1) group_post_exit(&group_sh[0]);
-    add_rays(S, st, nrays, STATS, gwave);
+    add_rays(S, st, nrays, STATS, gunit);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shadow: item = (group of 64 shading points, light).  Light loop body of render.hpp:184-206 up to the
-// occlusion decision; the contribution is stored and summed in light order by k_resolve.
+// k_shadow: item = (group of 64 shading points of depth `level`, light).  Light loop body of render.hpp:184-206 up
+// to the occlusion decision (is_occluded, :110-131); the contribution is stored and summed in light order later.
 template <bool STATS, int SLICES>
 __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     const RenderArgs &A = S.r;
-    // SLICES > 1: the workgroup's wave 0 owns the rays, waves 1.. help with large leaves (trace.hip.hpp)
     __shared__ GroupShared group_sh[1];
     const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (SLICES > 1 && wave_in_block != 0u) {
@@ -216,9 +301,21 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         return;
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gwave = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;    // work-unit id
-    const uint32_t n_waves = SLICES > 1 ? gridDim.x : gridDim.x * (blockDim.x >> 6);
-    const uint32_t n_hits = S.ws.ctrl[kCtrlHitCount + S.level];
+    const uint32_t gunit = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    const uint32_t n_units_grid = SLICES > 1 ? gridDim.x : gridDim.x * (blockDim.x >> 6);
+    uint32_t *ctrl = S.ws.ctrl;
+    if (ctrl[kCtrlOverflow] != 0u) {
+        if (SLICES > 1) group_post_exit(&group_sh[0]);
+        return;
+    }
+    uint32_t hit_base = 0u, n_hits = 0u;
+    {
+        unsigned long long hb = 0ull;
+        for (uint32_t j = 0; j < S.level; ++j) hb += ctrl[kCtrlHitCount + j];
+        const unsigned long long hc = ctrl[kCtrlHitCount + S.level];
+        hit_base = hb < S.ws.hit_cap ? (uint32_t)hb : S.ws.hit_cap;
+        n_hits = (hb + hc <= S.ws.hit_cap) ? (uint32_t)hc : S.ws.hit_cap - hit_base;
+    }
     const uint32_t n_lights = (uint32_t)A.n_lights;
     const uint32_t n_items = ((n_hits + 63u) >> 6) * n_lights;
     const float PI_F = 3.14159265358979323846f;
@@ -226,17 +323,12 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     SliceCtx sx = {SLICES > 1 ? &group_sh[0] : nullptr, A.slice_min_tris, 0u, true, 0u};
     uint32_t nrays = 0;
 
-#ifdef RTK_DEBUG_WAVE_TIME
-    const unsigned long long dbg_b0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    for (uint32_t item = gwave; item < n_items; item = next_item(S.ws.ctrl + kCtrlTicket + (kMaxRayDepth + 2) + S.level, n_waves)) {
-#ifdef RTK_DEBUG_WAVE_TIME
-        const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    for (uint32_t item = gunit; item < n_items; item = next_item(ctrl + kCtrlTicket + kLevels + S.level, n_units_grid)) {
         const uint32_t group = item / n_lights, k = item % n_lights;
-        const uint32_t h = group * 64u + lane;
-        const bool valid = h < n_hits;
-        const float4 *q = reinterpret_cast<const float4 *>(S.ws.hits + (valid ? h : 0u));
+        const uint32_t hl = group * 64u + lane;
+        const bool valid = hl < n_hits;
+        const uint32_t h = hit_base + (valid ? hl : 0u);
+        const float4 *q = reinterpret_cast<const float4 *>(S.ws.hits + h);
         const float4 a = q[0], b = q[1];
         const V3 P = mk(a.x, a.y, a.z), ncos = mk(b.x, b.y, b.z);
         const DevLight *L = A.lights + k;                                    // wave-uniform
@@ -247,51 +339,82 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         const float d0 = dot(ld, ncos);
         const float cosine = (0.0f < d0) ? d0 : 0.0f;                        // std::max(0, dot)
         const float contrib = (L->intensity / area) * cosine;
-        const bool shoot = valid & (0.0f < radius);                          // is_occluded's loop guard, render.hpp:114
-        const Ray ray = make_ray(P + (A.shadow_bias * ld), ld);
-        Cand c;
-        c.t = kFltMax; c.u = c.v = 0.f; c.k = kMiss;
-        c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, false, shoot, st, sx);
-        nrays += shoot ? 1u : 0u;
-        const bool clear = !shoot | (c.k == kMiss) | (radius < c.t);         // render.hpp:117 (no transmissive surface here)
-        if (valid) S.ws.contrib[(size_t)h * n_lights + k] = make_float2(contrib, clear ? 1.0f : 0.0f);
-#ifdef RTK_DEBUG_WAVE_TIME
-        if (lane == 0u && S.level < 4u) {
-            const uint32_t dt = (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_t0);
-            uint32_t *d = S.ws.ctrl + kCtrlDebug + (2u * 4u + S.level) * 4u;
-            atomicAdd(d + 0, dt); atomicMax(d + 1, dt); atomicAdd(d + 2, 1u);
+        Ray ray = make_ray(P + (A.shadow_bias * ld), ld);
+        float max_t = radius;
+        bool pending = valid & (0.0f < radius);                              // is_occluded's loop guard, render.hpp:114
+        bool clear = true;
+        while (wave_any(pending)) {
+            const Cand c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, false, pending, st, sx);
+            if (pending) {
+                nrays += 1u;
+                bool clr = (c.k == kMiss) | (max_t < c.t);                   // :117
+                bool again = false;
+                if (!clr && A.has_refractive) {
+                    const uint32_t m = A.tree.shade[A.tree.tri_ids[c.k]].material;
+                    if (A.materials[m].kind == RTK_MAT_REFRACTIVE) {         // transmissive: step through, :126-127
+                        const V3 hp = ray.o + (c.t * ray.d);
+                        ray.o = hp + (A.shadow_bias * ray.d);
+                        max_t -= c.t;
+                        if (0.0f < max_t) again = true; else clr = true;
+                    }
+                }
+                if (!again) { clear = clr; pending = false; }
+            }
         }
-#endif
+        if (valid) S.ws.contrib[(size_t)h * n_lights + k] = make_float2(contrib, clear ? 1.0f : 0.0f);
     }
-#ifdef RTK_DEBUG_WAVE_TIME
-    if (lane == 0u && S.level < 4u)
-        atomicMax(S.ws.ctrl + kCtrlDebug + (2u * 4u + S.level) * 4u + 3, (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_b0));
-#endif
     if (SLICES > 1) group_post_exit(&group_sh[0]);
-    add_rays(S, st, nrays, STATS, gwave);
+    add_rays(S, st, nrays, STATS, gunit);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_resolve: final_color += ((intensity / area) * cosine) * albedo for the unoccluded lights, in light order;
-// final_color /= (diffuse_reflection_ray_count + 1) with a count of 0 (render.hpp:205-208).
-__global__ __launch_bounds__(256) void k_resolve(StreamArgs S) {
+// k_combine: one thread per depth-`level` node.  Children (depth level+1) are final by now.
+__global__ __launch_bounds__(256) void k_combine(StreamArgs S) {
     const RenderArgs &A = S.r;
-    const uint32_t n_hits = S.ws.ctrl[kCtrlHitCount + S.level];
+    if (S.ws.ctrl[kCtrlOverflow] != 0u) return;                                // the megakernel redoes the frame
+    uint32_t base, count;
+    level_range(S.ws.ctrl + kCtrlNodeCount, S.n_root, S.level, S.ws.node_cap, base, count);
     const uint32_t n_lights = (uint32_t)A.n_lights;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n_hits; h += stride) {
-        const float4 *q = reinterpret_cast<const float4 *>(S.ws.hits + h);
-        const uint32_t pix = __float_as_uint(q[0].w), mat = __float_as_uint(q[1].w);
-        const DevMaterial *m = A.materials + mat;
-        const V3 albedo = mk(m->albedo[0], m->albedo[1], m->albedo[2]);
-        V3 acc = mk(0.f, 0.f, 0.f);
-        for (uint32_t k = 0; k < n_lights; ++k) {
-            const float2 cv = S.ws.contrib[(size_t)h * n_lights + k];
-            if (cv.y != 0.0f) acc = acc + (cv.x * albedo);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        NodeRes *nd = S.ws.nodes + base + i;
+        const float4 *q = reinterpret_cast<const float4 *>(nd);
+        const float4 a = q[0], b = q[1];
+        const uint32_t kind = __float_as_uint(a.w), first = __float_as_uint(b.x), aux = __float_as_uint(b.y),
+                       nchild = __float_as_uint(b.z), pix = __float_as_uint(b.w);
+        V3 v = mk(a.x, a.y, a.z);
+        if (kind == NODE_PASS) {                                               // render.hpp:249 / :275
+            const NodeRes *c = S.ws.nodes + first;
+            v = mk(c->value[0], c->value[1], c->value[2]);
+        } else if (kind == NODE_REFR) {                                        // :301
+            const NodeRes *c0 = S.ws.nodes + first, *c1 = c0 + 1;
+            const float fresnel = __uint_as_float(aux);
+            const V3 refr = mk(c0->value[0], c0->value[1], c0->value[2]), refl = mk(c1->value[0], c1->value[1], c1->value[2]);
+            v = (fresnel * refl) + ((1.0f - fresnel) * refr);
+        } else if (kind == NODE_DIFF) {                                        // :151-208
+            const HitRec *h = S.ws.hits + aux;
+            const DevMaterial *m = A.materials + h->mat;
+            const V3 albedo = mk(m->albedo[0], m->albedo[1], m->albedo[2]);
+            V3 acc = mk(0.f, 0.f, 0.f);
+            for (uint32_t g = 0; g < nchild; ++g) {                            // a GI ray that missed is worth 0: adding it changes nothing
+                const NodeRes *c = S.ws.nodes + first + g;
+                acc = acc + mk(c->value[0], c->value[1], c->value[2]);
+            }
+            for (uint32_t k = 0; k < n_lights; ++k) {
+                const float2 cv = S.ws.contrib[(size_t)aux * n_lights + k];
+                if (cv.y != 0.0f) acc = acc + (cv.x * albedo);
+            }
+            const float div = (float)(A.diffuse_rays + 1);
+            v = mk(acc.x / div, acc.y / div, acc.z / div);
         }
-        const float div = (float)(A.diffuse_rays + 1);
-        emit_pixel(S, pix, mk(acc.x / div, acc.y / div, acc.z / div));
+        if (kind != NODE_LEAF) { nd->value[0] = v.x; nd->value[1] = v.y; nd->value[2] = v.z; }
+        if (S.level == 0u && pix != 0xFFFFFFFFu) emit_pixel(S, pix, v);
     }
+}
+
+// zeroes the counters when the streamed frame overflowed (the megakernel that redoes it counts from scratch)
+__global__ void k_reset_counters_if(unsigned long long *counters, const uint32_t *flag) {
+    if (*flag != 0u && threadIdx.x < (unsigned)kCounterWords) counters[threadIdx.x] = 0ull;
 }
 
 }  // namespace dev
@@ -315,39 +438,31 @@ void launch_shadow(const dev::StreamArgs &S, bool stats, unsigned units, hipStre
 
 }  // namespace
 
-// One sample of one frame.  `slices` = waves per 64-ray work unit (1 or 4).
-hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int slices, hipStream_t s) {
+// One sample of one frame.
+hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, hipStream_t s) {
     dev::StreamArgs S = base;
     const dev::RenderArgs &A = S.r;
-    const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
-    const uint64_t tiles = (uint64_t)A.buckets_per_rank * bpb;
-    if (tiles == 0) return hipSuccess;
-    if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(S.ws.ctrl, 0, dev::kCtrlWords * sizeof(uint32_t), s);
+    if (S.n_root == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(S.ws.ctrl, 0, dev::kCtrlOverflow * sizeof(uint32_t), s);      // keeps the overflow word
     if (e != hipSuccess) return e;
-    // queue-driven stages are persistent: a fixed number of work units' worth of waves stride over the queue
-    // (8 waves per SIMD on 256 CUs = 8192 waves)
-    const unsigned persist_units = slices > 1 ? 8192u / (unsigned)slices : 8192u;
+    // queue-driven stages: 2048 work units in flight (8 waves per SIMD on 256 CUs, 4 waves per unit)
+    const unsigned persist_units = 2048u;
     for (int level = 0; level <= A.max_depth; ++level) {
         S.level = (uint32_t)level;
-        if (level == 0) {
-            if (slices > 1) launch_path<true, 4>(S, stats, (unsigned)tiles, s);
-            else launch_path<true, 1>(S, stats, (unsigned)tiles, s);
-        } else {
-            if (slices > 1) launch_path<false, 4>(S, stats, persist_units, s);
-            else launch_path<false, 1>(S, stats, persist_units, s);
-        }
-        if (level < A.max_depth) {
-            if (A.n_lights > 0) {
-                if (slices > 1) launch_shadow<4>(S, stats, persist_units, s);
-                else launch_shadow<1>(S, stats, persist_units, s);
-            }
-            hipLaunchKernelGGL(dev::k_resolve, dim3(1024), dim3(256), 0, s, S);
-        }
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
+        if (level == 0) launch_path<true, 4>(S, stats, S.n_root / 64u, s);
+        else launch_path<false, 4>(S, stats, persist_units, s);
+        if (level < A.max_depth && A.n_lights > 0) launch_shadow<4>(S, stats, persist_units, s);
     }
-    return hipSuccess;
+    for (int level = A.max_depth > 0 ? A.max_depth - 1 : 0; level >= 0; --level) {
+        S.level = (uint32_t)level;
+        hipLaunchKernelGGL(dev::k_combine, dim3(level == 0 ? 2048 : 1024), dim3(256), 0, s, S);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_overflow_reset(const dev::StreamArgs &S, hipStream_t s) {
+    hipLaunchKernelGGL(dev::k_reset_counters_if, dim3(1), dim3(128), 0, s, S.r.counters, S.ws.ctrl + dev::kCtrlOverflow);
+    return hipGetLastError();
 }
 
 }  // namespace rtk

@@ -1,4 +1,4 @@
-// Argument blocks of the streaming frame pipeline (stream.hip).
+// Argument blocks of the streaming ("wavefront") frame pipeline (stream.hip).
 #pragma once
 
 #include "kernels.hpp"
@@ -6,33 +6,60 @@
 namespace rtk {
 namespace dev {
 
-struct PathRay {            // 32 B: a reflection ray waiting for depth level d
+// One node of a sample's ray tree = one ray (camera ray or secondary ray).  48 bytes, three 16-byte slots.
+struct RayRec {
     float o[3];
-    uint32_t pixel;         // output index (in pixels) this path ends in
+    uint32_t parent;        // node id of the ray that spawned this one (unused for camera rays)
     float d[3];
+    uint32_t pixel;         // output index (in pixels) of the sample this ray belongs to
+    uint32_t key;           // RNG key (position in the ray tree, common.hip.hpp)
+    uint32_t info;          // bit 0: valid, bit 1: a miss is worth the background colour (else black)
+    uint32_t pad[2];
+};
+static_assert(sizeof(RayRec) == 48, "RayRec is three 16-byte slots");
+constexpr uint32_t kRayValid = 1u, kRayMissBackground = 2u;
+
+// What color_hit made of the ray (render/render.hpp:133-308).  32 bytes.
+struct NodeRes {
+    float value[3];         // the ray's colour once known (leaves: at once; inner nodes: after k_combine)
+    uint32_t kind;          // NODE_*
+    uint32_t first_child;   // children are contiguous node ids
+    uint32_t aux;           // NODE_REFR: fresnel (float bits); NODE_DIFF: index of the shading point
+    uint32_t n_children;
     uint32_t pad;
 };
+static_assert(sizeof(NodeRes) == 32, "NodeRes is two 16-byte slots");
+enum : uint32_t {
+    NODE_LEAF = 0,          // value is final: miss colour, depth limit, constant material
+    NODE_PASS = 1,          // reflective / total internal reflection: the value of the single child
+    NODE_REFR = 2,          // refractive: fresnel * child[1] + (1 - fresnel) * child[0]   (child 0 = refraction ray)
+    NODE_DIFF = 3           // diffuse: (sum of GI children, then unoccluded lights in order) / (diffuse_rays + 1)
+};
+
 struct HitRec {             // 32 B: a diffuse shading point waiting for its light loop
     float P[3];
-    uint32_t pixel;
+    uint32_t node;
     float ncos[3];          // the normal the cosine law uses (hit_normal if smooth_shading, else face_normal)
     uint32_t mat;
 };
-static_assert(sizeof(PathRay) == 32 && sizeof(HitRec) == 32, "queue records are two 16-byte stores");
+static_assert(sizeof(HitRec) == 32, "HitRec is two 16-byte stores");
 
-// control block (u32 words): queue fill counts per depth level
-constexpr uint32_t kCtrlPathCount = 0;                      // [kMaxRayDepth + 2]
-constexpr uint32_t kCtrlHitCount = kMaxRayDepth + 2;        // [kMaxRayDepth + 2]
-constexpr uint32_t kCtrlTicket = 2 * (kMaxRayDepth + 2);     // [2][kMaxRayDepth + 2] dynamic work-unit tickets (path, shadow)
-constexpr uint32_t kCtrlDebug = 4 * (kMaxRayDepth + 2);      // -DRTK_DEBUG_WAVE_TIME: [stage 0..2][level 0..3]{sum, max, n, block max}
-constexpr uint32_t kCtrlWords = kCtrlDebug + 3 * 4 * 4;
+// control block (u32 words)
+constexpr uint32_t kLevels = kMaxRayDepth + 2;
+constexpr uint32_t kCtrlNodeCount = 0;                      // [kLevels] ray-tree nodes per depth level
+constexpr uint32_t kCtrlHitCount = kLevels;                 // [kLevels] shading points per depth level
+constexpr uint32_t kCtrlTicket = 2 * kLevels;               // [2][kLevels] dynamic work-unit tickets (path, shadow)
+constexpr uint32_t kCtrlOverflow = 4 * kLevels;             // [1] set when a queue ran out of space: the frame is redone by the megakernel
+constexpr uint32_t kCtrlWords = 4 * kLevels + 4;
 
 struct StreamWs {
-    PathRay *path[2];       // ping-pong by level parity, capacity = pixels of this rank
-    HitRec *hits;           // capacity = pixels of this rank (reused by every level)
-    float2 *contrib;        // [capacity * n_lights] {contribution, unoccluded}
-    float *sumbuf;          // [capacity * 3] running sample sum (spp > 1 only)
+    RayRec *rays;           // [node_cap]
+    NodeRes *nodes;         // [node_cap]
+    HitRec *hits;           // [hit_cap]
+    float2 *contrib;        // [hit_cap * n_lights] {contribution, unoccluded}
+    float *sumbuf;          // [pixels * 3] running sample sum (spp > 1 only)
     uint32_t *ctrl;
+    uint32_t node_cap, hit_cap;
 };
 
 struct StreamArgs {
@@ -40,11 +67,12 @@ struct StreamArgs {
     StreamWs ws;
     uint32_t level;
     int sample;
-    uint32_t auto_min_lanes;   // RTK_TRACE_AUTO: leave the wave-cooperative walk when fewer rays than this share a node
+    uint32_t n_root;        // level-0 nodes: 64 per 8x8 pixel block of this rank
 };
 
 }  // namespace dev
 
-hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int slices, hipStream_t s);
+hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, hipStream_t s);
+hipError_t launch_stream_overflow_reset(const dev::StreamArgs &S, hipStream_t s);
 
 }  // namespace rtk
