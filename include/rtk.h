@@ -42,13 +42,13 @@ enum { RTK_MAT_DIFFUSE = 0, RTK_MAT_REFLECTIVE = 1, RTK_MAT_REFRACTIVE = 2, RTK_
 /* traversal strategy of the device kernels; all of them give bit-identical results */
 enum {
     RTK_TRACE_AUTO = 0,   /* batched intersect: wave-cooperative while the wave's rays agree, per-lane otherwise;
-                             frames: RTK_TRACE_GROUP4 */
+                             frames: RTK_TRACE_STREAM when the scene's ray trees fork (refraction, diffuse GI), else RTK_TRACE_GROUP4 */
     RTK_TRACE_LANE = 1,   /* one ray per lane, independent stackless traversal */
     RTK_TRACE_WAVE = 2,   /* one wave walks the tree once for its 64 rays (scalar node/triangle fetch) */
     RTK_TRACE_GROUP4 = 3, /* frames only: 4 waves share 64 rays and split every large leaf 4 ways (merge through LDS) */
     RTK_TRACE_GROUP8 = 4, /* frames only: same with 8 waves */
     RTK_TRACE_GROUP2 = 5, /* frames only: same with 2 waves */
-    RTK_TRACE_STREAM = 6, /* frames only, scenes without refraction/GI: per-depth path / shadow / resolve kernels with
+    RTK_TRACE_STREAM = 6, /* frames only: the ray tree level by level — per-depth path / shadow / combine kernels over
                              compacted ray queues (stream.hip) */
     RTK_TRACE_TWOPASS = 7 /* frames only, spp == 1: camera-ray pass, then the GROUP4 shading pass over the pixel blocks
                              sorted by estimated cost, most expensive first */

@@ -465,7 +465,9 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         RTK_HIP(hipMemsetAsync(d_out, 0, nf * sizeof(float), s));
     }
     // fork-free scenes (no refraction, no GI) can be rendered by the streaming pipeline (stream.hip)
-    const bool stream = p->trace_mode == RTK_TRACE_STREAM;
+    // RTK_TRACE_AUTO for frames: scenes whose ray trees fork (refraction, diffuse GI) go through the streaming pipeline
+    // (all rays of a depth level in parallel); fork-free scenes through the GROUP4 megakernel (fewer launches)
+    const bool stream = p->trace_mode == RTK_TRACE_STREAM || (p->trace_mode == RTK_TRACE_AUTO && forks);
     const bool twopass = p->trace_mode == RTK_TRACE_TWOPASS;
     if (twopass && p->spp != 1) return fail(RTK_ERR_UNSUPPORTED, "RTK_TRACE_TWOPASS needs spp == 1");
     if (twopass) {
@@ -488,11 +490,17 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         rc = ensure_stream_ws(a, out_pixels, n_root * factor + 4096, a->scene.lights.size(), p->spp > 1);
         if (rc != RTK_OK) return rc;
         dev::StreamArgs S;
-        S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root);
+        S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root); S.auto_min_lanes = 12;
+        // measured on MI355X: the workgroup-cooperative wave walk beats the per-lane walk at every depth, even for the
+        // incoherent rays behind refractive surfaces (tools/sweep_stream.sh), so no level switches strategy by default
+        int deep_level = 99, deep_mode = RTK_TRACE_AUTO;
+        if (const char *e = std::getenv("RTK_STREAM_DEEP_LEVEL")) deep_level = std::atoi(e);
+        if (const char *e = std::getenv("RTK_STREAM_DEEP_MODE")) deep_mode = std::atoi(e);
+        if (const char *e = std::getenv("RTK_AUTO_MIN_LANES")) { const int v = std::atoi(e); if (v > 0 && v <= 64) S.auto_min_lanes = uint32_t(v); }
         RTK_HIP(hipMemsetAsync(a->ws.ctrl, 0, dev::kCtrlWords * sizeof(uint32_t), s));
         for (int sample = 0; sample < p->spp; ++sample) {
             S.sample = sample;
-            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, s);
+            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, deep_level, deep_mode, s);
             if (es != hipSuccess) return hip_fail(es, "launch streaming pipeline");
         }
         // safety net: if any queue overflowed, the megakernel renders the frame again (a no-op otherwise)

@@ -138,9 +138,18 @@ __device__ __forceinline__ void store_ray(RayRec *dst, const V3 o, const V3 d, c
 // ------------------------------------------------------------------------------------------------
 // k_path: LEVEL0 = camera rays, one work unit per 8x8 pixel block (same bucket / rank mapping as k_render);
 // otherwise the depth-`level` nodes, units of 64 consecutive nodes drawn from a ticket.
-template <bool LEVEL0, bool STATS, int SLICES>
+template <bool LEVEL0, bool STATS, int SLICES, int MODE>
 __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     const RenderArgs &A = S.r;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
+    constexpr bool kStage = (MODE != RTK_TRACE_WAVE);          // the per-lane walk reads the node array from LDS
+    if (kStage) {
+        const float4 *src = reinterpret_cast<const float4 *>(A.tree.nodes);
+        float4 *dst = reinterpret_cast<float4 *>(lds_nodes);
+        for (uint32_t i = threadIdx.x; i < A.tree.n_nodes * 2u; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
     // SLICES > 1: the workgroup's wave 0 owns the rays, waves 1.. help with large leaves (trace.hip.hpp)
     __shared__ GroupShared group_sh[1];
     const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
             miss_bg = (info & kRayMissBackground) != 0u;
             ray = make_ray(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z));
         }
-        const Cand c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, LEVEL0, valid, st, sx);
+        const Cand c = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, LEVEL0, valid, st, sx, S.auto_min_lanes);
         nrays += valid ? 1u : 0u;
 
         // ---- color_hit's material switch (render.hpp:133-308): node kind + the rays it spawns
@@ -291,9 +300,18 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
 // ------------------------------------------------------------------------------------------------
 // k_shadow: item = (group of 64 shading points of depth `level`, light).  Light loop body of render.hpp:184-206 up
 // to the occlusion decision (is_occluded, :110-131); the contribution is stored and summed in light order later.
-template <bool STATS, int SLICES>
+template <bool STATS, int SLICES, int MODE>
 __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     const RenderArgs &A = S.r;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
+    constexpr bool kStage = (MODE != RTK_TRACE_WAVE);
+    if (kStage) {
+        const float4 *src = reinterpret_cast<const float4 *>(A.tree.nodes);
+        float4 *dst = reinterpret_cast<float4 *>(lds_nodes);
+        for (uint32_t i = threadIdx.x; i < A.tree.n_nodes * 2u; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
     __shared__ GroupShared group_sh[1];
     const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (SLICES > 1 && wave_in_block != 0u) {
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         bool pending = valid & (0.0f < radius);                              // is_occluded's loop guard, render.hpp:114
         bool clear = true;
         while (wave_any(pending)) {
-            const Cand c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, false, pending, st, sx);
+            const Cand c = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, false, pending, st, sx, S.auto_min_lanes);
             if (pending) {
                 nrays += 1u;
                 bool clr = (c.k == kMiss) | (max_t < c.t);                   // :117
@@ -423,35 +441,46 @@ __global__ void k_reset_counters_if(unsigned long long *counters, const uint32_t
 
 namespace {
 
-template <bool LEVEL0, int SLICES>
+template <bool LEVEL0, int SLICES, int MODE>
 void launch_path(const dev::StreamArgs &S, bool stats, unsigned units, hipStream_t s) {
     const unsigned blocks = SLICES > 1 ? units : (units + 3) / 4, threads = SLICES > 1 ? 64u * SLICES : 256u;
-    if (stats) hipLaunchKernelGGL((dev::k_path<LEVEL0, true, SLICES>), dim3(blocks), dim3(threads), 0, s, S);
-    else hipLaunchKernelGGL((dev::k_path<LEVEL0, false, SLICES>), dim3(blocks), dim3(threads), 0, s, S);
+    const size_t lds = MODE != RTK_TRACE_WAVE ? (size_t)S.r.tree.n_nodes * sizeof(DevNode) : 0;
+    if (stats) hipLaunchKernelGGL((dev::k_path<LEVEL0, true, SLICES, MODE>), dim3(blocks), dim3(threads), lds, s, S);
+    else hipLaunchKernelGGL((dev::k_path<LEVEL0, false, SLICES, MODE>), dim3(blocks), dim3(threads), lds, s, S);
 }
-template <int SLICES>
+template <int SLICES, int MODE>
 void launch_shadow(const dev::StreamArgs &S, bool stats, unsigned units, hipStream_t s) {
     const unsigned blocks = SLICES > 1 ? units : (units + 3) / 4, threads = SLICES > 1 ? 64u * SLICES : 256u;
-    if (stats) hipLaunchKernelGGL((dev::k_shadow<true, SLICES>), dim3(blocks), dim3(threads), 0, s, S);
-    else hipLaunchKernelGGL((dev::k_shadow<false, SLICES>), dim3(blocks), dim3(threads), 0, s, S);
+    const size_t lds = MODE != RTK_TRACE_WAVE ? (size_t)S.r.tree.n_nodes * sizeof(DevNode) : 0;
+    if (stats) hipLaunchKernelGGL((dev::k_shadow<true, SLICES, MODE>), dim3(blocks), dim3(threads), lds, s, S);
+    else hipLaunchKernelGGL((dev::k_shadow<false, SLICES, MODE>), dim3(blocks), dim3(threads), lds, s, S);
 }
 
 }  // namespace
 
-// One sample of one frame.
-hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, hipStream_t s) {
+// One sample of one frame.  Depth levels below `deep_level` use the workgroup-cooperative wave walk (coherent rays);
+// from `deep_level` on the rays of a unit have little in common and `deep_mode` (RTK_TRACE_AUTO / _LANE / _WAVE) applies.
+hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, hipStream_t s) {
     dev::StreamArgs S = base;
     const dev::RenderArgs &A = S.r;
     if (S.n_root == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(S.ws.ctrl, 0, dev::kCtrlOverflow * sizeof(uint32_t), s);      // keeps the overflow word
     if (e != hipSuccess) return e;
-    // queue-driven stages: 2048 work units in flight (8 waves per SIMD on 256 CUs, 4 waves per unit)
-    const unsigned persist_units = 2048u;
+    if ((size_t)A.tree.n_nodes * sizeof(DevNode) > kMaxNodeLdsBytes) deep_mode = RTK_TRACE_WAVE;
+    // queue-driven stages: 8192 waves in flight (8 per SIMD on 256 CUs)
+    const unsigned group_units = 2048u, wave_units = 8192u;
     for (int level = 0; level <= A.max_depth; ++level) {
         S.level = (uint32_t)level;
-        if (level == 0) launch_path<true, 4>(S, stats, S.n_root / 64u, s);
-        else launch_path<false, 4>(S, stats, persist_units, s);
-        if (level < A.max_depth && A.n_lights > 0) launch_shadow<4>(S, stats, persist_units, s);
+        const bool deep = level >= deep_level && deep_mode != RTK_TRACE_WAVE;
+        if (level == 0) launch_path<true, 4, RTK_TRACE_WAVE>(S, stats, S.n_root / 64u, s);
+        else if (!deep) launch_path<false, 4, RTK_TRACE_WAVE>(S, stats, group_units, s);
+        else if (deep_mode == RTK_TRACE_LANE) launch_path<false, 1, RTK_TRACE_LANE>(S, stats, wave_units, s);
+        else launch_path<false, 1, RTK_TRACE_AUTO>(S, stats, wave_units, s);
+        if (level < A.max_depth && A.n_lights > 0) {
+            if (!deep) launch_shadow<4, RTK_TRACE_WAVE>(S, stats, group_units, s);
+            else if (deep_mode == RTK_TRACE_LANE) launch_shadow<1, RTK_TRACE_LANE>(S, stats, wave_units, s);
+            else launch_shadow<1, RTK_TRACE_AUTO>(S, stats, wave_units, s);
+        }
     }
     for (int level = A.max_depth > 0 ? A.max_depth - 1 : 0; level >= 0; --level) {
         S.level = (uint32_t)level;

@@ -68,11 +68,12 @@ struct StreamArgs {
     uint32_t level;
     int sample;
     uint32_t n_root;        // level-0 nodes: 64 per 8x8 pixel block of this rank
+    uint32_t auto_min_lanes; // RTK_TRACE_AUTO: leave the wave-cooperative walk when fewer rays than this share a node
 };
 
 }  // namespace dev
 
-hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, hipStream_t s);
+hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, hipStream_t s);
 hipError_t launch_stream_overflow_reset(const dev::StreamArgs &S, hipStream_t s);
 
 }  // namespace rtk

@@ -17,7 +17,7 @@ only = sys.argv[1:]
 for cname, (path, kw) in CASES.items():
     if only and not any(o in cname for o in only): continue
     acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(path))
-    for mode in (0, 1, 2, 3, 6, 7):
+    for mode in [int(m) for m in os.environ.get("TC_MODES", "0 1 2 3 6 7").split()]:
         cfg = rtk.RenderConfig(trace_mode=mode, **kw)
         out = torch.empty((acc.output_floats(cfg),), dtype=torch.float32, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
