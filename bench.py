@@ -26,6 +26,22 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 TRACE_NAMES = {0: "auto", 1: "lane", 2: "wave", 3: "group4", 4: "group8", 5: "group2", 6: "stream", 7: "twopass"}
 
 
+def measured_traffic(mode_name: str):
+    """HBM bytes per k_render launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json): FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
+    prescribes for gfx950.  None when no profile of this traversal mode is committed."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("trace_mode") in (mode_name, {"auto": "group4", "group4": "auto"}.get(mode_name)) and d.get("workload") == "config2":
+            best = d
+    return best
+
+
 def algorithmic_bytes(c: dict) -> int:
     """B = 32 B per node popped + 36 B per triangle tested + 32 B ray in + 32 B hit out, summed over rays."""
     return 32 * c["nodes"] + 36 * c["tris"] + 64 * c["rays"]
@@ -39,12 +55,12 @@ def cpu_baseline(seconds: float) -> dict:
     oracle.build()
     w = oracle.native_width()
     acc = oracle.Accel(oracle.Scene(oracle.load_crtscene(SCENE), fast=True), oracle.ACCEL_KD_SIMD, W=w)
-    acc.render(WIDTH, HEIGHT, SPP, DEPTH, DIFFUSE)  # warm-up (page faults, thread start)
+    acc.render(WIDTH, HEIGHT, SPP, DEPTH, DIFFUSE, count_work=False)  # warm-up (page faults, thread start)
     times, rays = [], 0
     t_end = time.time() + seconds
     while time.time() < t_end or len(times) < 3:
         t0 = time.perf_counter()
-        _, cn = acc.render(WIDTH, HEIGHT, SPP, DEPTH, DIFFUSE)
+        _, cn = acc.render(WIDTH, HEIGHT, SPP, DEPTH, DIFFUSE, count_work=False)   # rays/hits only: no per-triangle tallies
         times.append(time.perf_counter() - t0)
         rays = cn["rays"]
     best = min(times)
@@ -146,6 +162,7 @@ def main() -> None:
         ms_per_step = elapsed / args.steps * 1e3
         # the dominant kernel is k_render; one launch processes this rank's share of the frame
         launch_bytes = algorithmic_bytes(work)
+        traffic = measured_traffic(TRACE_NAMES[args.trace_mode]) if world == 1 else None
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
             "metric": "Mrays/s (intersect invocations per second), hw09/scene5 dragon 1920x1080 1spp",
@@ -161,10 +178,11 @@ def main() -> None:
             "config": {"workload": "BASELINE configs[1]: scenes/hw09/scene5.crtscene 1920x1080 1spp max_ray_depth=5 "
                                    "(primary + shadow + reflection rays), kd_tree_simd_accel semantics",
                        "rays_per_frame": int(rays_total), "primary_rays": WIDTH * HEIGHT * SPP,
-                       "trace_mode": TRACE_NAMES[args.trace_mode], "parallelism": f"bucket-tiles x{world}"},
+                       "trace_mode": TRACE_NAMES[args.trace_mode] + (" (= group4 for this fork-free scene)" if args.trace_mode == 0 else ""), "parallelism": f"bucket-tiles x{world}"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
+                "traffic_source": (traffic or {}).get("source"),
                 "kernel": "k_render", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "bytes_per_ray": launch_bytes / max(work["rays"], 1),

@@ -91,6 +91,7 @@ class _RenderParams(C.Structure):
         ("reflection_bias", C.c_float),
         ("refraction_bias", C.c_float),
         ("n_threads", C.c_int32),
+        ("count_work", C.c_int32),
     ]
 
 
@@ -309,9 +310,10 @@ class Accel:
         return out
 
     def render(self, width=0, height=0, spp=1, max_depth=5, diffuse_rays=0, seed=42, fov_degrees=90.0,
-               shadow_bias=1e-4, reflection_bias=1e-4, refraction_bias=1e-4, n_threads=0):
+               shadow_bias=1e-4, reflection_bias=1e-4, refraction_bias=1e-4, n_threads=0, count_work=True):
         p = _RenderParams(width, height, spp, max_depth, diffuse_rays, seed, fov_degrees,
-                          np.float32(shadow_bias), np.float32(reflection_bias), np.float32(refraction_bias), n_threads)
+                          np.float32(shadow_bias), np.float32(reflection_bias), np.float32(refraction_bias), n_threads,
+                          1 if count_work else 0)
         w = width or self.scene.flat.width
         h = height or self.scene.flat.height
         rgb = np.zeros((h, w, 3), np.float32)

@@ -82,17 +82,20 @@ static void aabb_split(const aabb3 *b, unsigned axis, aabb3 *b0, aabb3 *b1) {   
     else { b0->max.z = mid; b1->min.z = mid; }
 }
 /* aabb3.hpp:74-90 — slab test; NaN handling follows std::minmax/max/min exactly. */
+#define SLAB_AXIS(lo_, hi_, o_, inv_)                                        \
+    do {                                                                     \
+        const float a_ = ((lo_) - (o_)) * (inv_), c_ = ((hi_) - (o_)) * (inv_); \
+        const float t1_ = (c_ < a_) ? c_ : a_;   /* std::minmax(a,c).first  */ \
+        const float t2_ = (c_ < a_) ? a_ : c_;   /* std::minmax(a,c).second */ \
+        t_min = (t_min < t1_) ? t1_ : t_min;     /* std::max(t_min,t1) */    \
+        t_max = (t2_ < t_max) ? t2_ : t_max;     /* std::min(t_max,t2) */    \
+        if (t_max < t_min) return 0;                                         \
+    } while (0)
 static inline int aabb_ray(const aabb3 *b, const ray3 *r, float *out_tmin) {
     float t_min = 0.0f, t_max = FLT_MAX;
-    for (int axis = 0; axis < 3; ++axis) {
-        const float a = (get3(b->min, axis) - get3(r->origin, axis)) * get3(r->inv_direction, axis);
-        const float c = (get3(b->max, axis) - get3(r->origin, axis)) * get3(r->inv_direction, axis);
-        const float t1 = (c < a) ? c : a;   /* std::minmax(a,c).first  */
-        const float t2 = (c < a) ? a : c;   /* std::minmax(a,c).second */
-        t_min = (t_min < t1) ? t1 : t_min;  /* std::max(t_min,t1) */
-        t_max = (t2 < t_max) ? t2 : t_max;  /* std::min(t_max,t2) */
-        if (t_max < t_min) return 0;
-    }
+    SLAB_AXIS(b->min.x, b->max.x, r->origin.x, r->inv_direction.x);
+    SLAB_AXIS(b->min.y, b->max.y, r->origin.y, r->inv_direction.y);
+    SLAB_AXIS(b->min.z, b->max.z, r->origin.z, r->inv_direction.z);
     *out_tmin = t_min;
     return 1;
 }
@@ -356,41 +359,46 @@ void ora_accel_dump(const ora_accel *a, float *nodes_box, int32_t *nodes_link, i
 typedef struct { float t, u, v; int32_t tri; int found; } candidate;
 
 /* kd_tree_simd.hpp:25-60 (W-wide Möller–Trumbore) + :266-302 (leaf loop, hmin, first-set lane).
- * The lane loops are written so that gcc vectorises them at the build's native width. */
+ * Written with GCC vector extensions so that every arithmetic line is one W-wide instruction, like the
+ * std::experimental::simd code of the reference (W = 16: one zmm register, W = 8: one ymm, W = 4: one xmm). */
 #define DEFINE_LEAF_SIMD(W_)                                                                                   \
+typedef float vf##W_ __attribute__((vector_size(4 * W_), aligned(4 * W_)));                                    \
+typedef int32_t vi##W_ __attribute__((vector_size(4 * W_), aligned(4 * W_)));                                  \
 static candidate leaf_simd_##W_(const ora_accel *a, const ray3 *r, const kd_node *leaf, int cull, uint64_t *cn) { \
     candidate best; best.found = 0; best.t = FLT_MAX; best.u = best.v = 0.f; best.tri = -1;                    \
     const float eps = a->eps;                                                                                  \
     const float dx = r->direction.x, dy = r->direction.y, dz = r->direction.z;                                 \
     const float ox = r->origin.x, oy = r->origin.y, oz = r->origin.z;                                          \
+    const vi##W_ absmask = (vi##W_){0} + 0x7FFFFFFF;                                                           \
     for (int32_t pi = leaf->start_idx; pi < leaf->start_idx + leaf->count; ++pi) {                             \
         const tri_packet *p = &a->packs[pi];                                                                   \
-        float t[W_] __attribute__((aligned(64))), u[W_] __attribute__((aligned(64))), v[W_] __attribute__((aligned(64))); \
-        int32_t mask[W_] __attribute__((aligned(64)));                                                         \
-        int any = 0;                                                                                           \
-        for (int l = 0; l < W_; ++l) {                                                                         \
-            const float pvx = dy * p->e2z[l] - dz * p->e2y[l];                                                 \
-            const float pvy = dz * p->e2x[l] - dx * p->e2z[l];                                                 \
-            const float pvz = dx * p->e2y[l] - dy * p->e2x[l];                                                 \
-            const float det = p->e1x[l] * pvx + p->e1y[l] * pvy + p->e1z[l] * pvz;                             \
-            int m = cull ? (eps <= det) : (eps <= fabsf(det));                                                 \
-            const float inv_det = 1.0f / det;                                                                  \
-            const float tvx = ox - p->v0x[l], tvy = oy - p->v0y[l], tvz = oz - p->v0z[l];                      \
-            const float uu = (tvx * pvx + tvy * pvy + tvz * pvz) * inv_det;                                    \
-            m &= (0.0f <= uu) & (uu <= 1.0f);                                                                  \
-            const float qx = tvy * p->e1z[l] - tvz * p->e1y[l];                                                \
-            const float qy = tvz * p->e1x[l] - tvx * p->e1z[l];                                                \
-            const float qz = tvx * p->e1y[l] - tvy * p->e1x[l];                                                \
-            const float vv = (dx * qx + dy * qy + dz * qz) * inv_det;                                          \
-            m &= (0.0f <= vv) & (uu + vv <= 1.0f);                                                             \
-            const float tt = (p->e2x[l] * qx + p->e2y[l] * qy + p->e2z[l] * qz) * inv_det;                     \
-            m &= (eps < tt);                                                                                   \
-            t[l] = tt; u[l] = uu; v[l] = vv; mask[l] = m; any |= m;                                            \
-        }                                                                                                      \
+        const vf##W_ v0x = *(const vf##W_ *)p->v0x, v0y = *(const vf##W_ *)p->v0y, v0z = *(const vf##W_ *)p->v0z; \
+        const vf##W_ e1x = *(const vf##W_ *)p->e1x, e1y = *(const vf##W_ *)p->e1y, e1z = *(const vf##W_ *)p->e1z; \
+        const vf##W_ e2x = *(const vf##W_ *)p->e2x, e2y = *(const vf##W_ *)p->e2y, e2z = *(const vf##W_ *)p->e2z; \
+        const vf##W_ pvx = dy * e2z - dz * e2y;                                                                \
+        const vf##W_ pvy = dz * e2x - dx * e2z;                                                                \
+        const vf##W_ pvz = dx * e2y - dy * e2x;                                                                \
+        const vf##W_ det = e1x * pvx + e1y * pvy + e1z * pvz;                                                  \
+        const vf##W_ adet = (vf##W_)((vi##W_)det & absmask);                                                   \
+        vi##W_ m = cull ? (eps <= det) : (eps <= adet);                                                        \
+        const vf##W_ inv_det = 1.0f / det;                                                                     \
+        const vf##W_ tvx = ox - v0x, tvy = oy - v0y, tvz = oz - v0z;                                           \
+        const vf##W_ u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv_det;                                        \
+        m &= (0.0f <= u) & (u <= 1.0f);                                                                        \
+        const vf##W_ qx = tvy * e1z - tvz * e1y;                                                               \
+        const vf##W_ qy = tvz * e1x - tvx * e1z;                                                               \
+        const vf##W_ qz = tvx * e1y - tvy * e1x;                                                               \
+        const vf##W_ v = (dx * qx + dy * qy + dz * qz) * inv_det;                                              \
+        m &= (0.0f <= v) & (u + v <= 1.0f);                                                                    \
+        vf##W_ t = (e2x * qx + e2y * qy + e2z * qz) * inv_det;                                                 \
+        m &= (eps < t);                                                                                        \
         if (cn) cn[ORA_C_PACKETS] += 1;                                                                        \
+        int any = 0;                                                                                           \
+        for (int l = 0; l < W_; ++l) any |= m[l];                                                              \
         if (!any) continue;                                           /* none_of(mask) :276 */                 \
         const float best_t = best.found ? best.t : FLT_MAX;           /* :280 */                               \
-        for (int l = 0; l < W_; ++l) t[l] = mask[l] ? t[l] : best_t;  /* where(!mask,t)=best_t :281 */         \
+        const vf##W_ bt = (vf##W_){0} + best_t;                                                                \
+        t = (vf##W_)(((vi##W_)t & m) | ((vi##W_)bt & ~m));            /* where(!mask,t)=best_t :281 */         \
         float t_min = t[0];                                                                                    \
         for (int l = 1; l < W_; ++l) t_min = (t[l] < t_min) ? t[l] : t_min;   /* hmin :283 */                  \
         if (best_t <= t_min) continue;                                /* :284 */                               \
@@ -471,11 +479,14 @@ typedef struct {                                 /* render/hit.hpp:9-21 (uvs omi
 #define ORA_STACK_CAP 256
 
 /* kd_tree_simd.hpp:187-264 and kd_tree.hpp:82-162. */
-static int accel_intersect(const ora_accel *a, const ray3 *ray, int cull, hit_rec *out, uint64_t *cn) {
+/* cn: ORA_C_RAYS / ORA_C_HITS are always counted; the per-node / per-triangle tallies only when cn[ORA_C_COUNT] != 0
+ * (a detail flag stored one past the counters) so that a timed baseline run does not pay for them. */
+static int accel_intersect(const ora_accel *a, const ray3 *ray, int cull, hit_rec *out, uint64_t *cn_all) {
+    uint64_t *cn = (cn_all && cn_all[ORA_C_COUNT]) ? cn_all : NULL;
     candidate closest; closest.found = 0; closest.t = FLT_MAX; closest.u = closest.v = 0.f; closest.tri = -1;
     int32_t stack[ORA_STACK_CAP]; int sp = 0;
     stack[sp++] = 0;
-    if (cn) cn[ORA_C_RAYS] += 1;
+    if (cn_all) cn_all[ORA_C_RAYS] += 1;
     while (sp > 0) {
         const kd_node *node = &a->tree[stack[--sp]];
         if (cn) cn[ORA_C_NODES] += 1;
@@ -511,7 +522,7 @@ static int accel_intersect(const ora_accel *a, const ray3 *ray, int cull, hit_re
         }
     }
     if (!closest.found) return 0;
-    if (cn) cn[ORA_C_HITS] += 1;
+    if (cn_all) cn_all[ORA_C_HITS] += 1;
     const triangle *tr = &a->triangles[closest.tri];
     const mesh_object *mesh = &a->scene->meshes[tr->mesh_idx];
     const float u = closest.u, v = closest.v;
@@ -529,11 +540,14 @@ static int accel_intersect(const ora_accel *a, const ray3 *ray, int cull, hit_re
 }
 
 void ora_intersect(const ora_accel *a, const float *rays, size_t n, int cull, ora_hit *out, uint64_t *counters) {
+    uint64_t local[ORA_C_COUNT + 1];
+    memset(local, 0, sizeof(local));
+    local[ORA_C_COUNT] = 1;
     for (size_t i = 0; i < n; ++i) {
         const float *r = &rays[i * 6];
         const ray3 ray = mkray(mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]));
         hit_rec h;
-        if (accel_intersect(a, &ray, cull, &h, counters)) {
+        if (accel_intersect(a, &ray, cull, &h, counters ? local : NULL)) {
             out[i].t = h.distance; out[i].u = h.u; out[i].v = h.v; out[i].tri = h.tri_idx; out[i].mesh = h.mesh_idx;
             out[i].normal[0] = h.hit_normal.x; out[i].normal[1] = h.hit_normal.y; out[i].normal[2] = h.hit_normal.z;
         } else {
@@ -541,6 +555,7 @@ void ora_intersect(const ora_accel *a, const float *rays, size_t n, int cull, or
             out[i].normal[0] = out[i].normal[1] = out[i].normal[2] = 0.f;
         }
     }
+    if (counters) for (int k = 0; k < ORA_C_COUNT; ++k) counters[k] += local[k];
 }
 
 /* ------------------------------------------------------------------ RNG / trig shared with the HIP path */
@@ -617,7 +632,7 @@ typedef struct {
 } frame_ctx;
 
 typedef struct {
-    uint64_t cn[ORA_C_COUNT];
+    uint64_t cn[ORA_C_COUNT + 1];     /* [ORA_C_COUNT] = detail flag, see accel_intersect */
 } thread_ctx;
 
 typedef struct { float r, g, b; } col;
@@ -814,7 +829,7 @@ int ora_render_frame(const ora_accel *a, const ora_render_params *p, float *rgb,
     if (nt > 1024) nt = 1024;
     worker_arg *args = (worker_arg *)calloc((size_t)nt, sizeof(worker_arg));
     pthread_t *th = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
-    for (int i = 0; i < nt; ++i) { args[i].f = &f; }
+    for (int i = 0; i < nt; ++i) { args[i].f = &f; args[i].tc.cn[ORA_C_COUNT] = p->count_work ? 1u : 0u; }
     if (nt == 1) worker(&args[0]);
     else {
         for (int i = 0; i < nt; ++i) pthread_create(&th[i], NULL, worker, &args[i]);

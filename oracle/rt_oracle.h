@@ -65,6 +65,7 @@ typedef struct {
     double fov_degrees;
     float shadow_bias, reflection_bias, refraction_bias;
     int32_t n_threads;             /* 0 = hardware concurrency */
+    int32_t count_work;            /* 1 = also tally nodes / boxes / leaves / packets / triangles (slower) */
 } ora_render_params;
 
 /* 32-byte hit record, same layout as rtk_hit in include/rtk.h. */
