@@ -60,7 +60,7 @@ struct rtk_accel {
     rtk::DevLight *d_lights = nullptr;
     unsigned long long *d_counters = nullptr;     // 8 x u64 in rtk_counters order + kRayCounterShards ray-count shards
     // streaming-pipeline workspace (grown on demand)
-    rtk::dev::StreamWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    rtk::dev::StreamWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr, nullptr};
     size_t ws_pixels = 0, ws_lights = 0, ws_nodes = 0;
     bool ws_sum = false;
     // two-pass workspace
@@ -126,7 +126,8 @@ int ensure_stream_ws(rtk_accel *a, size_t pixels, size_t nodes, size_t lights, b
     RTK_HIP(hipDeviceSynchronize());
     (void)hipFree(a->ws.rays); (void)hipFree(a->ws.nodes); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
     (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
-    a->ws = dev::StreamWs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    (void)hipFree(a->ws.node_bins); (void)hipFree(a->ws.hit_bins); (void)hipFree(a->ws.node_order); (void)hipFree(a->ws.hit_order);
+    a->ws = dev::StreamWs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr, nullptr};
     a->ws_pixels = 0; a->ws_nodes = 0; a->ws_lights = 0; a->ws_sum = false;
     const size_t nh = nn / 2 + 64;                            // every shading point belongs to a distinct node
     RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.rays), nn * sizeof(dev::RayRec)));
@@ -135,6 +136,10 @@ int ensure_stream_ws(rtk_accel *a, size_t pixels, size_t nodes, size_t lights, b
     RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.contrib), nh * nl * sizeof(float2)));
     if (sum) RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.sumbuf), np * 3 * sizeof(float)));
     RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.ctrl), dev::kCtrlWords * sizeof(uint32_t)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.node_bins), dev::kSortBins * sizeof(uint32_t)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.hit_bins), dev::kSortBins * sizeof(uint32_t)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.node_order), nn * sizeof(uint32_t)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.hit_order), nh * sizeof(uint32_t)));
     a->ws.node_cap = uint32_t(nn); a->ws.hit_cap = uint32_t(nh);
     a->ws_pixels = np; a->ws_nodes = nn; a->ws_lights = nl; a->ws_sum = sum;
     return RTK_OK;
@@ -352,6 +357,7 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
         (void)hipFree(a->ws.rays); (void)hipFree(a->ws.nodes); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
         (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
+        (void)hipFree(a->ws.node_bins); (void)hipFree(a->ws.hit_bins); (void)hipFree(a->ws.node_order); (void)hipFree(a->ws.hit_order);
         (void)hipFree(a->tp_prim); (void)hipFree(a->tp_bins); (void)hipFree(a->tp_bin_list); (void)hipFree(a->tp_order);
     }
     delete a;
@@ -497,10 +503,21 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         if (const char *e = std::getenv("RTK_STREAM_DEEP_LEVEL")) deep_level = std::atoi(e);
         if (const char *e = std::getenv("RTK_STREAM_DEEP_MODE")) deep_mode = std::atoi(e);
         if (const char *e = std::getenv("RTK_AUTO_MIN_LANES")) { const int v = std::atoi(e); if (v > 0 && v <= 64) S.auto_min_lanes = uint32_t(v); }
+        int sort_from = forks ? 1 : 99;                        // fork-free trees stay coherent; sorting would only add launches
+        if (const char *e = std::getenv("RTK_STREAM_SORT_FROM")) sort_from = std::atoi(e);
+        {
+            const DevNode &root = a->tree.dev_nodes[0];
+            for (int k = 0; k < 3; ++k) {
+                const float ext = root.hi[k] - root.lo[k];
+                S.grid_lo[k] = root.lo[k];
+                S.grid_scale[k] = (ext > 0.f && ext < 3.0e38f) ? 16.0f / ext : 0.f;
+            }
+        }
+        S.nodes_sorted = S.hits_sorted = S.bin_children = S.bin_hits = 0;
         RTK_HIP(hipMemsetAsync(a->ws.ctrl, 0, dev::kCtrlWords * sizeof(uint32_t), s));
         for (int sample = 0; sample < p->spp; ++sample) {
             S.sample = sample;
-            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, deep_level, deep_mode, s);
+            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, deep_level, deep_mode, sort_from, s);
             if (es != hipSuccess) return hip_fail(es, "launch streaming pipeline");
         }
         // safety net: if any queue overflowed, the megakernel renders the frame again (a no-op otherwise)

@@ -125,6 +125,19 @@ __device__ __forceinline__ void add_rays(const StreamArgs &S, const Stats &st, c
     if (__lane_id() == 0u && total != 0u) atomicAdd(c + 8 + (shard % (uint32_t)kRayCounterShards), (unsigned long long)total);
 }
 
+__device__ __forceinline__ uint32_t grid_cell(const StreamArgs &S, const V3 p) {
+    const float fx = (p.x - S.grid_lo[0]) * S.grid_scale[0], fy = (p.y - S.grid_lo[1]) * S.grid_scale[1],
+                fz = (p.z - S.grid_lo[2]) * S.grid_scale[2];
+    const uint32_t cx = fx > 0.f ? (fx < 15.f ? (uint32_t)fx : 15u) : 0u;        // NaN compares false -> cell 0
+    const uint32_t cy = fy > 0.f ? (fy < 15.f ? (uint32_t)fy : 15u) : 0u;
+    const uint32_t cz = fz > 0.f ? (fz < 15.f ? (uint32_t)fz : 15u) : 0u;
+    return (cx << 8) | (cy << 4) | cz;
+}
+__device__ __forceinline__ uint32_t ray_sort_key(const StreamArgs &S, const V3 o, const V3 d) {
+    const uint32_t octant = (d.x > 0.f ? 1u : 0u) | (d.y > 0.f ? 2u : 0u) | (d.z > 0.f ? 4u : 0u);
+    return (octant << 12) | grid_cell(S, o);
+}
+
 __device__ __forceinline__ void store_ray(RayRec *dst, const V3 o, const V3 d, const uint32_t parent, const uint32_t pixel,
                                           const uint32_t key, const uint32_t info) {
     float4 *q = reinterpret_cast<float4 *>(dst);
@@ -180,8 +193,12 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     uint32_t nrays = 0;
 
     for (uint32_t item = gunit; item < n_items; item = LEVEL0 ? n_items : next_item(ctrl + kCtrlTicket + level, n_units_grid)) {
-        const uint32_t node = base + item * 64u + lane;
         const bool in_range = item * 64u + lane < count;
+        uint32_t node = base + item * 64u + lane;
+        if (!LEVEL0 && S.nodes_sorted) {
+            node = in_range ? S.ws.node_order[item * 64u + lane] : base;
+            node = node < S.ws.node_cap ? node : S.ws.node_cap - 1u;          // never trust an index read from memory
+        }
         bool valid = in_range;
         uint32_t pix = 0xFFFFFFFFu, key = 0u;
         bool miss_bg = true;
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
             key = root_key(pcg_hash(A.seed), py * A.width + px, (uint32_t)S.sample);
             ray = camera_ray(A, px, py, key);
         } else {
-            const float4 *q = reinterpret_cast<const float4 *>(S.ws.rays + (in_range ? node : base));
+            const float4 *q = reinterpret_cast<const float4 *>(S.ws.rays + node);
             const float4 a = q[0], b = q[1], c = q[2];
             pix = __float_as_uint(b.w);
             key = __float_as_uint(c.x);
@@ -265,12 +282,17 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
         const uint32_t first_child = next_base + child_slot;
         if (kind == NODE_PASS || kind == NODE_REFR) {
             store_ray(S.ws.rays + first_child, c0o, c0d, node, pix, child_key(key, 0u), kRayValid | (c0_bg ? kRayMissBackground : 0u));
-            if (kind == NODE_REFR) store_ray(S.ws.rays + first_child + 1u, c1o, c1d, node, pix, child_key(key, 1u), kRayValid);
+            if (S.bin_children) atomicAdd(S.ws.node_bins + ray_sort_key(S, c0o, c0d), 1u);
+            if (kind == NODE_REFR) {
+                store_ray(S.ws.rays + first_child + 1u, c1o, c1d, node, pix, child_key(key, 1u), kRayValid);
+                if (S.bin_children) atomicAdd(S.ws.node_bins + ray_sort_key(S, c1o, c1d), 1u);
+            }
         } else if (kind == NODE_DIFF) {
             aux = hit_base + hit_slot;
             float4 *q = reinterpret_cast<float4 *>(S.ws.hits + aux);
             q[0] = make_float4(P.x, P.y, P.z, __uint_as_float(node));
             q[1] = make_float4(ncos.x, ncos.y, ncos.z, __uint_as_float(mat));
+            if (S.bin_hits) atomicAdd(S.ws.hit_bins + grid_cell(S, P), 1u);
             for (uint32_t gi = 0; gi < nchild; ++gi) {                                          // GI rays, :151-176
                 const V3 right = normalized(cross(ray.d, hn));
                 const V3 up = hn;
@@ -285,6 +307,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
                 const V3 dir = mk(right.x * rv.x + right.y * rv.y + right.z * rv.z, up.x * rv.x + up.y * rv.y + up.z * rv.z,
                                   fwd.x * rv.x + fwd.y * rv.y + fwd.z * rv.z);
                 store_ray(S.ws.rays + first_child + gi, org, dir, node, pix, child_key(key, gi), kRayValid);
+                if (S.bin_children) atomicAdd(S.ws.node_bins + ray_sort_key(S, org, dir), 1u);
             }
         }
         if (in_range) {
@@ -345,7 +368,11 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         const uint32_t group = item / n_lights, k = item % n_lights;
         const uint32_t hl = group * 64u + lane;
         const bool valid = hl < n_hits;
-        const uint32_t h = hit_base + (valid ? hl : 0u);
+        uint32_t h = hit_base + (valid ? hl : 0u);
+        if (S.hits_sorted) {
+            h = valid ? S.ws.hit_order[hl] : hit_base;
+            h = h < S.ws.hit_cap ? h : S.ws.hit_cap - 1u;
+        }
         const float4 *q = reinterpret_cast<const float4 *>(S.ws.hits + h);
         const float4 a = q[0], b = q[1];
         const V3 P = mk(a.x, a.y, a.z), ncos = mk(b.x, b.y, b.z);
@@ -383,6 +410,56 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     }
     if (SLICES > 1) group_post_exit(&group_sh[0]);
     add_rays(S, st, nrays, STATS, gunit);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Counting sort of a level's rays / shading points (see kSortBins): k_path filled the histogram while appending;
+// k_sort_scan turns it into start offsets, k_sort_scatter_* hands every record a slot.
+__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t *bins) {
+    __shared__ uint32_t part[1024];
+    constexpr uint32_t per = kSortBins / 1024u;
+    uint32_t local[per];
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; ++i) { local[i] = bins[threadIdx.x * per + i]; sum += local[i]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t i = 0; i < per; ++i) { bins[threadIdx.x * per + i] = run; run += local[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_sort_scatter_nodes(StreamArgs S) {
+    if (S.ws.ctrl[kCtrlOverflow] != 0u) return;
+    uint32_t base, count;
+    level_range(S.ws.ctrl + kCtrlNodeCount, S.n_root, S.level, S.ws.node_cap, base, count);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float4 *q = reinterpret_cast<const float4 *>(S.ws.rays + base + i);
+        const float4 a = q[0], b = q[1];
+        const uint32_t slot = atomicAdd(S.ws.node_bins + ray_sort_key(S, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z)), 1u);
+        if (slot < count) S.ws.node_order[slot] = base + i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sort_scatter_hits(StreamArgs S) {
+    const uint32_t *ctrl = S.ws.ctrl;
+    if (ctrl[kCtrlOverflow] != 0u) return;
+    unsigned long long hb = 0ull;
+    for (uint32_t j = 0; j < S.level; ++j) hb += ctrl[kCtrlHitCount + j];
+    const unsigned long long hc = ctrl[kCtrlHitCount + S.level];
+    const uint32_t hit_base = hb < S.ws.hit_cap ? (uint32_t)hb : S.ws.hit_cap;
+    const uint32_t n_hits = (hb + hc <= S.ws.hit_cap) ? (uint32_t)hc : S.ws.hit_cap - hit_base;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += stride) {
+        const float4 a = *reinterpret_cast<const float4 *>(S.ws.hits + hit_base + i);
+        const uint32_t slot = atomicAdd(S.ws.hit_bins + grid_cell(S, mk(a.x, a.y, a.z)), 1u);
+        if (slot < n_hits) S.ws.hit_order[slot] = hit_base + i;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -459,27 +536,53 @@ void launch_shadow(const dev::StreamArgs &S, bool stats, unsigned units, hipStre
 }  // namespace
 
 // One sample of one frame.  Depth levels below `deep_level` use the workgroup-cooperative wave walk (coherent rays);
-// from `deep_level` on the rays of a unit have little in common and `deep_mode` (RTK_TRACE_AUTO / _LANE / _WAVE) applies.
-hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, hipStream_t s) {
+// from `deep_level` on `deep_mode` (RTK_TRACE_AUTO / _LANE / _WAVE) applies.  From depth `sort_from_level` on, the
+// level's rays and shading points are counting-sorted for coherence before they are cut into 64-ray work units.
+hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, int sort_from_level,
+                                hipStream_t s) {
     dev::StreamArgs S = base;
     const dev::RenderArgs &A = S.r;
     if (S.n_root == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(S.ws.ctrl, 0, dev::kCtrlOverflow * sizeof(uint32_t), s);      // keeps the overflow word
     if (e != hipSuccess) return e;
     if ((size_t)A.tree.n_nodes * sizeof(DevNode) > kMaxNodeLdsBytes) deep_mode = RTK_TRACE_WAVE;
+    if (sort_from_level < 1) sort_from_level = 1;
+    if (sort_from_level <= A.max_depth) {
+        e = hipMemsetAsync(S.ws.node_bins, 0, dev::kSortBins * sizeof(uint32_t), s);
+        if (e == hipSuccess) e = hipMemsetAsync(S.ws.hit_bins, 0, dev::kSortBins * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+    }
     // queue-driven stages: 8192 waves in flight (8 per SIMD on 256 CUs)
     const unsigned group_units = 2048u, wave_units = 8192u;
     for (int level = 0; level <= A.max_depth; ++level) {
         S.level = (uint32_t)level;
         const bool deep = level >= deep_level && deep_mode != RTK_TRACE_WAVE;
+        S.nodes_sorted = (level >= sort_from_level) ? 1u : 0u;
+        S.hits_sorted = (level >= sort_from_level && level < A.max_depth) ? 1u : 0u;
+        S.bin_children = (level + 1 >= sort_from_level && level < A.max_depth) ? 1u : 0u;
+        S.bin_hits = S.hits_sorted;
         if (level == 0) launch_path<true, 4, RTK_TRACE_WAVE>(S, stats, S.n_root / 64u, s);
         else if (!deep) launch_path<false, 4, RTK_TRACE_WAVE>(S, stats, group_units, s);
         else if (deep_mode == RTK_TRACE_LANE) launch_path<false, 1, RTK_TRACE_LANE>(S, stats, wave_units, s);
         else launch_path<false, 1, RTK_TRACE_AUTO>(S, stats, wave_units, s);
         if (level < A.max_depth && A.n_lights > 0) {
+            if (S.hits_sorted) {
+                hipLaunchKernelGGL(dev::k_sort_scan, dim3(1), dim3(1024), 0, s, S.ws.hit_bins);
+                hipLaunchKernelGGL(dev::k_sort_scatter_hits, dim3(1024), dim3(256), 0, s, S);
+                e = hipMemsetAsync(S.ws.hit_bins, 0, dev::kSortBins * sizeof(uint32_t), s);
+                if (e != hipSuccess) return e;
+            }
             if (!deep) launch_shadow<4, RTK_TRACE_WAVE>(S, stats, group_units, s);
             else if (deep_mode == RTK_TRACE_LANE) launch_shadow<1, RTK_TRACE_LANE>(S, stats, wave_units, s);
             else launch_shadow<1, RTK_TRACE_AUTO>(S, stats, wave_units, s);
+        }
+        if (S.bin_children) {                                  // order the next level's rays
+            dev::StreamArgs N = S;
+            N.level = (uint32_t)level + 1u;
+            hipLaunchKernelGGL(dev::k_sort_scan, dim3(1), dim3(1024), 0, s, S.ws.node_bins);
+            hipLaunchKernelGGL(dev::k_sort_scatter_nodes, dim3(1024), dim3(256), 0, s, N);
+            e = hipMemsetAsync(S.ws.node_bins, 0, dev::kSortBins * sizeof(uint32_t), s);
+            if (e != hipSuccess) return e;
         }
     }
     for (int level = A.max_depth > 0 ? A.max_depth - 1 : 0; level >= 0; --level) {

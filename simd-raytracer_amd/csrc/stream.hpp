@@ -52,6 +52,11 @@ constexpr uint32_t kCtrlTicket = 2 * kLevels;               // [2][kLevels] dyna
 constexpr uint32_t kCtrlOverflow = 4 * kLevels;             // [1] set when a queue ran out of space: the frame is redone by the megakernel
 constexpr uint32_t kCtrlWords = 4 * kLevels + 4;
 
+// Coherence sort (deep levels of forking ray trees): rays are binned by direction octant (major) and a 16^3 grid cell
+// of their origin inside the scene box; shading points by the cell of their position.  Counting sort, all sizes on
+// the device.  Only the ORDER in which 64-ray work units are formed changes — never a result.
+constexpr uint32_t kSortBins = 8u * 4096u;
+
 struct StreamWs {
     RayRec *rays;           // [node_cap]
     NodeRes *nodes;         // [node_cap]
@@ -60,6 +65,10 @@ struct StreamWs {
     float *sumbuf;          // [pixels * 3] running sample sum (spp > 1 only)
     uint32_t *ctrl;
     uint32_t node_cap, hit_cap;
+    uint32_t *node_bins;    // [kSortBins] histogram -> offsets -> cursors of the next level's rays
+    uint32_t *hit_bins;     // [kSortBins] same for this level's shading points
+    uint32_t *node_order;   // [node_cap] node ids of the current level in sorted order
+    uint32_t *hit_order;    // [hit_cap] hit ids of the current level in sorted order
 };
 
 struct StreamArgs {
@@ -69,11 +78,17 @@ struct StreamArgs {
     int sample;
     uint32_t n_root;        // level-0 nodes: 64 per 8x8 pixel block of this rank
     uint32_t auto_min_lanes; // RTK_TRACE_AUTO: leave the wave-cooperative walk when fewer rays than this share a node
+    uint32_t nodes_sorted;   // k_path: this level's nodes are taken through ws.node_order
+    uint32_t hits_sorted;    // k_shadow: this level's shading points are taken through ws.hit_order
+    uint32_t bin_children;   // k_path: histogram the rays it spawns (the next level will be sorted)
+    uint32_t bin_hits;       // k_path: histogram the shading points it appends
+    float grid_lo[3], grid_scale[3];   // cell = clamp((p - lo) * scale, 0, 15)
 };
 
 }  // namespace dev
 
-hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, hipStream_t s);
+hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, int sort_from_level,
+                                hipStream_t s);
 hipError_t launch_stream_overflow_reset(const dev::StreamArgs &S, hipStream_t s);
 
 }  // namespace rtk
