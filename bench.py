@@ -93,13 +93,14 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if rank == 0:
-        ge.build()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()
+    if rank == 0:
+        ge.build()                      # a no-op when the in-tree libraries are current (they travel with the snapshot)
+    if world > 1:
+        dist.barrier()                  # nobody loads librtk_hip.so while rank 0 might still be writing it
     rtk = importlib.import_module("simd-raytracer_amd")
 
     accel = rtk.KdTreeSimdAccel(rtk.parse_scene_file(SCENE), device=local_rank)
@@ -191,7 +192,7 @@ def main() -> None:
                         "the tree (<0.3 MB) is LDS/scalar-cache/L2 resident, see DESIGN.md",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
