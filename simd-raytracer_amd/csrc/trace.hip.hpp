@@ -169,11 +169,17 @@ __device__ __forceinline__ bool wave_any(const bool p) { return __builtin_amdgcn
 struct TriS {      // one leaf reference held in SGPRs (wave-uniform)
     float v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z;
 };
+// One 32-byte scalar load (v0, e1, e2x, e2y) + one dword (e2z).  As ONE load the first eight floats cannot be split by
+// the compiler into "needed now" and "needed later" halves: split, the later half was sunk to the end of the loop
+// body, right in front of the wait, which exposed a full scalar-cache round trip in every iteration.
+typedef float float8_t __attribute__((ext_vector_type(8)));
+typedef const float8_t __attribute__((address_space(4))) *cptr_f32x8;
 __device__ __forceinline__ TriS load_tri_uniform(cptr_f32 tp) {
+    const float8_t a = *(cptr_f32x8)(const void __attribute__((address_space(4))) *)tp;
     TriS t;
-    t.v0x = tp[0]; t.v0y = tp[1]; t.v0z = tp[2];
-    t.e1x = tp[3]; t.e1y = tp[4]; t.e1z = tp[5];
-    t.e2x = tp[6]; t.e2y = tp[7]; t.e2z = tp[8];
+    t.v0x = a[0]; t.v0y = a[1]; t.v0z = a[2];
+    t.e1x = a[3]; t.e1y = a[4]; t.e1z = a[5];
+    t.e2x = a[6]; t.e2y = a[7]; t.e2z = tp[8];
     return t;
 }
 
@@ -183,6 +189,11 @@ __device__ __forceinline__ TriS load_tri_uniform(cptr_f32 tp) {
 __device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t first, const uint32_t lo, const uint32_t hi,
                                                 const Ray &r, const bool cull, const float eps, const bool pass, Cand &best) {
     if (lo >= hi) return;
+    // The per-lane predicate of the reference's mask (`mask &= ...`, kd_tree_simd.hpp:33-57) is carried as a 64-bit
+    // wave mask in SGPRs: every comparison is one v_cmp writing a lane mask, the ANDs and the "is anybody left"
+    // early-outs run on the scalar unit.
+    const unsigned long long pass_mask = __builtin_amdgcn_ballot_w64(pass);
+    const uint32_t lane = __lane_id();
     cptr_f32 tp = tris + ((size_t)first + lo) * 9;
     TriS cur = load_tri_uniform(tp);
     for (uint32_t k = lo; k < hi; ++k) {
@@ -192,22 +203,24 @@ __device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t fi
         const float pvy = r.d.z * cur.e2x - r.d.x * cur.e2z;
         const float pvz = r.d.x * cur.e2y - r.d.y * cur.e2x;
         const float det = cur.e1x * pvx + cur.e1y * pvy + cur.e1z * pvz;
-        bool m = pass & (eps <= (cull ? det : __builtin_fabsf(det)));
-        if (wave_any(m)) {
+        unsigned long long m = pass_mask & __builtin_amdgcn_ballot_w64(eps <= (cull ? det : __builtin_fabsf(det)));
+        if (m != 0ull) {
             const float inv_det = (1.0f / det);
             const float tvx = r.o.x - cur.v0x, tvy = r.o.y - cur.v0y, tvz = r.o.z - cur.v0z;
             const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv_det;
-            m = m & (0.0f <= u) & (u <= 1.0f);
-            if (wave_any(m)) {
+            m &= __builtin_amdgcn_ballot_w64(0.0f <= u) & __builtin_amdgcn_ballot_w64(u <= 1.0f);
+            if (m != 0ull) {
                 const float qx = tvy * cur.e1z - tvz * cur.e1y;
                 const float qy = tvz * cur.e1x - tvx * cur.e1z;
                 const float qz = tvx * cur.e1y - tvy * cur.e1x;
                 const float v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv_det;
-                m = m & (0.0f <= v) & (u + v <= 1.0f);
-                if (wave_any(m)) {
+                m &= __builtin_amdgcn_ballot_w64(0.0f <= v) & __builtin_amdgcn_ballot_w64(u + v <= 1.0f);
+                if (m != 0ull) {
                     const float t = (cur.e2x * qx + cur.e2y * qy + cur.e2z * qz) * inv_det;
-                    m = m & (eps < t) & (t < best.t);
-                    if (m) { best.t = t; best.u = u; best.v = v; best.k = first + k; }
+                    m &= __builtin_amdgcn_ballot_w64(eps < t) & __builtin_amdgcn_ballot_w64(t < best.t);
+                    if (m != 0ull) {
+                        if ((m >> lane) & 1ull) { best.t = t; best.u = u; best.v = v; best.k = first + k; }
+                    }
                 }
             }
         }
