@@ -183,7 +183,7 @@ def load_crtscene(path: str) -> FlatScene:
         if t == "diffuse" and not isinstance(m["albedo"], list):
             raise NotImplementedError("texture materials are out of scope (SURVEY.md §8f)")
         kinds.append(_KIND[t])
-        alb.append(m.get("albedo", [0, 0, 0]) if t != "refractive" else [0, 0, 0])
+        alb.append(list(m.get("albedo", [0, 0, 0]))[:3] if t != "refractive" else [0, 0, 0])
         ior.append(m.get("ior", 1.0) if t == "refractive" else 1.0)
         smooth.append(1 if m["smooth_shading"] else 0)
     mm, nv, nt, verts, idx = [], [], [], [], []
@@ -210,11 +210,11 @@ def load_crtscene(path: str) -> FlatScene:
         mat_albedo=np.asarray(alb, np.float64).astype(np.float32).reshape(-1, 3),
         mat_ior=np.asarray(ior, np.float64).astype(np.float32),
         mat_smooth=np.asarray(smooth, np.int32),
-        light_pos=np.asarray([l["position"] for l in lights], np.float64).astype(np.float32).reshape(-1, 3),
+        light_pos=np.asarray([l["position"][:3] for l in lights], np.float64).astype(np.float32).reshape(-1, 3),  # load_vec3 reads at(0..2), loader.hpp:19-26 (hw15/scene1 has a 4-component position)
         light_intensity=np.asarray([l["intensity"] for l in lights], np.float64).astype(np.float32),
-        cam_pos=np.asarray(doc["camera"]["position"], np.float64).astype(np.float32),
-        cam_mat=np.asarray(doc["camera"]["matrix"], np.float64).astype(np.float32),
-        background=np.asarray(st["background_color"], np.float64).astype(np.float32),
+        cam_pos=np.asarray(doc["camera"]["position"][:3], np.float64).astype(np.float32),
+        cam_mat=np.asarray(doc["camera"]["matrix"][:9], np.float64).astype(np.float32),
+        background=np.asarray(st["background_color"][:3], np.float64).astype(np.float32),
         width=int(img["width"]),
         height=int(img["height"]),
         bucket_size=int(img.get("bucket_size", 64)),  # loader.hpp:48
