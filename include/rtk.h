@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTK_ABI_VERSION 1
+#define RTK_ABI_VERSION 2
 
 /* status codes (reference: intersect is noexcept, miss = nullopt, kd_tree_simd.hpp:188,231;
  * loader throws std::invalid_argument, io/json/loader.hpp:104,127,145,170,190,224) */
@@ -33,11 +33,14 @@ enum {
     RTK_ERR_HIP = 3,          /* a HIP runtime call failed */
     RTK_ERR_IO = 4,           /* file could not be read / written */
     RTK_ERR_PARSE = 5,        /* .crtscene is not valid JSON or misses a required key */
-    RTK_ERR_UNSUPPORTED = 6   /* feature outside the accelerated path (texture materials) */
+    RTK_ERR_UNSUPPORTED = 6   /* feature outside the accelerated path (bitmap textures) */
 };
 
-/* material kinds: scene/material/material.hpp:12 (texture_material is out of scope) */
-enum { RTK_MAT_DIFFUSE = 0, RTK_MAT_REFLECTIVE = 1, RTK_MAT_REFRACTIVE = 2, RTK_MAT_CONSTANT = 3 };
+/* material kinds: scene/material/material.hpp:12 */
+enum { RTK_MAT_DIFFUSE = 0, RTK_MAT_REFLECTIVE = 1, RTK_MAT_REFRACTIVE = 2, RTK_MAT_CONSTANT = 3, RTK_MAT_TEXTURE = 4 };
+
+/* texture kinds: scene/texture/texture.hpp:13 (bitmap_texture needs an image decoder and is not supported) */
+enum { RTK_TEX_ALBEDO = 0, RTK_TEX_EDGES = 1, RTK_TEX_CHECKER = 2 };
 
 /* traversal strategy of the device kernels; all of them give bit-identical results */
 enum {
@@ -70,6 +73,15 @@ typedef struct {
     const float *mat_albedo;        /* [n_materials][3] */
     const float *mat_ior;           /* [n_materials] */
     const int32_t *mat_smooth;      /* [n_materials] smooth_shading */
+    const int32_t *mat_texture;     /* [n_materials] texture index for RTK_MAT_TEXTURE, ignored otherwise; may be NULL */
+    const float *uvs;               /* concatenated per-vertex (u, v) of the meshes with mesh_has_uvs != 0, in mesh order
+                                       (loader.hpp:173-192 keeps the first two of every three numbers); may be NULL */
+    const int32_t *mesh_has_uvs;    /* [n_meshes] 1 = the mesh has nverts uv pairs in `uvs`, 0 = all-zero uvs; may be NULL */
+    int32_t n_textures;             /* scene::textures (scene/scene.hpp:18), referenced by index instead of by name */
+    const int32_t *tex_kind;        /* [n_textures] RTK_TEX_* */
+    const float *tex_color_a;       /* [n_textures][3] albedo / edge_color / color_A */
+    const float *tex_color_b;       /* [n_textures][3] (unused) / inner_color / color_B */
+    const float *tex_param;         /* [n_textures] (unused) / edge_width / square_size */
     int32_t n_lights;
     const float *light_pos;         /* [n_lights][3] */
     const float *light_intensity;   /* [n_lights] */
@@ -84,6 +96,7 @@ typedef struct {
     int32_t n_meshes, n_materials, n_lights;
     int32_t n_vertices, n_triangles;
     int32_t width, height, bucket_size;
+    int32_t n_textures, n_uv_vertices;   /* n_uv_vertices = vertices of the meshes that carry uvs */
 } rtk_scene_info;
 
 /* template parameters of kd_tree_simd_accel (kd_tree_simd.hpp:63-67) as runtime values */
@@ -155,6 +168,9 @@ int rtk_scene_get_arrays(const rtk_scene *scene, int32_t *mesh_material, int32_t
                          float *vertices, uint32_t *indices, int32_t *mat_kind, float *mat_albedo, float *mat_ior,
                          int32_t *mat_smooth, float *light_pos, float *light_intensity, float *cam_pos,
                          float *cam_mat, float *background);
+/* texture side of the scene: [n_materials], [n_meshes], [n_uv_vertices][2], [n_textures], [n_textures][3] x2, [n_textures] */
+int rtk_scene_get_textures(const rtk_scene *scene, int32_t *mat_texture, int32_t *mesh_has_uvs, float *uvs,
+                           int32_t *tex_kind, float *tex_color_a, float *tex_color_b, float *tex_param);
 /* mesh_object::vertex_normals (scene/object/mesh.hpp:25-43), [nverts of that mesh][3] */
 int rtk_scene_vertex_normals(const rtk_scene *scene, int32_t mesh, float *out);
 void rtk_scene_destroy(rtk_scene *scene);

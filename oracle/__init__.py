@@ -18,7 +18,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-MAT_DIFFUSE, MAT_REFLECTIVE, MAT_REFRACTIVE, MAT_CONSTANT = 0, 1, 2, 3
+MAT_DIFFUSE, MAT_REFLECTIVE, MAT_REFRACTIVE, MAT_CONSTANT, MAT_TEXTURE = 0, 1, 2, 3, 4
+TEX_ALBEDO, TEX_EDGES, TEX_CHECKER = 0, 1, 2
 ACCEL_KD_SIMD, ACCEL_KD_SCALAR = 0, 1
 C_RAYS, C_HITS, C_NODES, C_BOXPASS, C_LEAVES, C_PACKETS, C_TRIS, C_PRIMARY, C_COUNT = range(9)
 COUNTER_NAMES = ["rays", "hits", "nodes", "boxpass", "leaves", "packets", "tris", "primary"]
@@ -66,6 +67,14 @@ class _SceneDesc(C.Structure):
         ("mat_albedo", C.POINTER(C.c_float)),
         ("mat_ior", C.POINTER(C.c_float)),
         ("mat_smooth", C.POINTER(C.c_int32)),
+        ("mat_texture", C.POINTER(C.c_int32)),
+        ("uvs", C.POINTER(C.c_float)),
+        ("mesh_has_uvs", C.POINTER(C.c_int32)),
+        ("n_textures", C.c_int32),
+        ("tex_kind", C.POINTER(C.c_int32)),
+        ("tex_color_a", C.POINTER(C.c_float)),
+        ("tex_color_b", C.POINTER(C.c_float)),
+        ("tex_param", C.POINTER(C.c_float)),
         ("n_lights", C.c_int32),
         ("light_pos", C.POINTER(C.c_float)),
         ("light_intensity", C.POINTER(C.c_float)),
@@ -165,6 +174,13 @@ class FlatScene:
     width: int
     height: int
     bucket_size: int
+    mat_texture: np.ndarray = None
+    uvs: np.ndarray = None            # concatenated [., 2] of the meshes with uvs
+    mesh_has_uvs: np.ndarray = None
+    tex_kind: np.ndarray = None
+    tex_color_a: np.ndarray = None
+    tex_color_b: np.ndarray = None
+    tex_param: np.ndarray = None
     extra: dict = field(default_factory=dict)
 
 
@@ -174,19 +190,41 @@ def load_crtscene(path: str) -> FlatScene:
         doc = json.load(f)
     st = doc["settings"]
     img = st["image_settings"]
+    tex_names, tkind, ta, tb, tp, tbitmap = [], [], [], [], [], []
+    for t in doc.get("textures", []) if isinstance(doc.get("textures", []), list) else []:      # loader.hpp:78-106
+        ty = t["type"]
+        tex_names.append(t["name"])
+        tbitmap.append(ty == "bitmap")
+        if ty == "albedo":
+            tkind.append(TEX_ALBEDO); ta.append(t["albedo"][:3]); tb.append([0, 0, 0]); tp.append(0.0)
+        elif ty == "edges":
+            tkind.append(TEX_EDGES); ta.append(t["edge_color"][:3]); tb.append(t["inner_color"][:3]); tp.append(t["edge_width"])
+        elif ty == "checker":
+            tkind.append(TEX_CHECKER); ta.append(t["color_A"][:3]); tb.append(t["color_B"][:3]); tp.append(t["square_size"])
+        elif ty == "bitmap":
+            tkind.append(TEX_ALBEDO); ta.append([0, 0, 0]); tb.append([0, 0, 0]); tp.append(0.0)
+        else:
+            raise ValueError("texture type unknown")  # loader.hpp:104
     mats = doc["materials"]
-    kinds, alb, ior, smooth = [], [], [], []
+    kinds, alb, ior, smooth, mtex = [], [], [], [], []
     for m in mats:
         t = m["type"]
         if t not in _KIND:
             raise ValueError("material type unknown")  # loader.hpp:145
-        if t == "diffuse" and not isinstance(m["albedo"], list):
-            raise NotImplementedError("texture materials are out of scope (SURVEY.md §8f)")
-        kinds.append(_KIND[t])
-        alb.append(list(m.get("albedo", [0, 0, 0]))[:3] if t != "refractive" else [0, 0, 0])
+        tex = -1
+        if t == "diffuse" and isinstance(m["albedo"], str):          # texture_material, loader.hpp:120-125
+            tex = tex_names.index(m["albedo"])
+            if tbitmap[tex]:
+                raise NotImplementedError("bitmap textures need an image decoder (SURVEY.md §8f)")
+            kinds.append(MAT_TEXTURE)
+            alb.append([0, 0, 0])
+        else:
+            kinds.append(_KIND[t])
+            alb.append(list(m.get("albedo", [0, 0, 0]))[:3] if t != "refractive" else [0, 0, 0])
+        mtex.append(tex)
         ior.append(m.get("ior", 1.0) if t == "refractive" else 1.0)
         smooth.append(1 if m["smooth_shading"] else 0)
-    mm, nv, nt, verts, idx = [], [], [], [], []
+    mm, nv, nt, verts, idx, uvl, has_uv = [], [], [], [], [], [], []
     for o in doc["objects"]:
         v = np.asarray(o["vertices"], dtype=np.float64)
         if v.size % 3:
@@ -199,6 +237,14 @@ def load_crtscene(path: str) -> FlatScene:
         nt.append(t.size // 3)
         verts.append(v.reshape(-1, 3).astype(np.float32))
         idx.append(t.reshape(-1, 3).astype(np.uint32))
+        uv = np.asarray(o.get("uvs", []), dtype=np.float64)
+        if uv.size:                                                       # loader.hpp:173-192: (u, v, ignored) triples
+            if uv.size % 3:
+                raise ValueError("uv coordinates not multiple of 3")
+            uvl.append(uv.reshape(-1, 3)[: v.size // 3, :2].astype(np.float32))
+            has_uv.append(1)
+        else:
+            has_uv.append(0)
     lights = doc["lights"]
     return FlatScene(
         mesh_material=np.asarray(mm, np.int32),
@@ -218,6 +264,13 @@ def load_crtscene(path: str) -> FlatScene:
         width=int(img["width"]),
         height=int(img["height"]),
         bucket_size=int(img.get("bucket_size", 64)),  # loader.hpp:48
+        mat_texture=np.asarray(mtex, np.int32),
+        uvs=np.ascontiguousarray(np.concatenate(uvl) if uvl else np.zeros((0, 2), np.float32)),
+        mesh_has_uvs=np.asarray(has_uv, np.int32),
+        tex_kind=np.asarray(tkind, np.int32),
+        tex_color_a=np.asarray(ta, np.float64).astype(np.float32).reshape(-1, 3),
+        tex_color_b=np.asarray(tb, np.float64).astype(np.float32).reshape(-1, 3),
+        tex_param=np.asarray(tp, np.float64).astype(np.float32),
     )
 
 
@@ -242,6 +295,20 @@ class Scene:
         d.mat_albedo = _p(flat.mat_albedo, C.c_float)
         d.mat_ior = _p(flat.mat_ior, C.c_float)
         d.mat_smooth = _p(flat.mat_smooth, C.c_int32)
+        self._tex = dict(
+            mt=flat.mat_texture if flat.mat_texture is not None else np.full(len(flat.mat_kind), -1, np.int32),
+            uv=flat.uvs if flat.uvs is not None else np.zeros((0, 2), np.float32),
+            hu=flat.mesh_has_uvs if flat.mesh_has_uvs is not None else np.zeros(len(flat.mesh_material), np.int32),
+            tk=flat.tex_kind if flat.tex_kind is not None else np.zeros(0, np.int32),
+            ta=flat.tex_color_a if flat.tex_color_a is not None else np.zeros((0, 3), np.float32),
+            tb=flat.tex_color_b if flat.tex_color_b is not None else np.zeros((0, 3), np.float32),
+            tp=flat.tex_param if flat.tex_param is not None else np.zeros(0, np.float32),
+        )
+        self._tex = {k: np.ascontiguousarray(v) for k, v in self._tex.items()}
+        d.mat_texture, d.uvs, d.mesh_has_uvs = _p(self._tex["mt"], C.c_int32), _p(self._tex["uv"], C.c_float), _p(self._tex["hu"], C.c_int32)
+        d.n_textures = len(self._tex["tk"])
+        d.tex_kind, d.tex_color_a = _p(self._tex["tk"], C.c_int32), _p(self._tex["ta"], C.c_float)
+        d.tex_color_b, d.tex_param = _p(self._tex["tb"], C.c_float), _p(self._tex["tp"], C.c_float)
         d.n_lights = len(flat.light_intensity)
         d.light_pos = _p(flat.light_pos, C.c_float)
         d.light_intensity = _p(flat.light_intensity, C.c_float)

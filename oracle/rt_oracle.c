@@ -107,6 +107,7 @@ typedef struct {                                /* scene/primitive/triangle.hpp:
     uint32_t vi[3];
     uint32_t mesh_idx;
     aabb3 box;
+    float uvs[6];                               /* vec3<vec2<F>> uvs, triangle.hpp:18 */
 } triangle;
 
 typedef struct {                                /* scene/object/mesh.hpp:15-44 */
@@ -118,12 +119,14 @@ typedef struct {                                /* scene/object/mesh.hpp:15-44 *
     aabb3 box;
 } mesh_object;
 
-typedef struct { int32_t kind; float albedo[3]; float ior; int32_t smooth; } material;
+typedef struct { int32_t kind; float albedo[3]; float ior; int32_t smooth; int32_t texture; } material;
+typedef struct { int32_t kind; float a[3], b[3]; float param; } texture;   /* scene/texture/{albedo,edge,checker}.hpp */
 typedef struct { v3 position; float intensity; } light;
 
 struct ora_scene {
     int32_t n_meshes; mesh_object *meshes;
     int32_t n_materials; material *materials;
+    int32_t n_textures; texture *textures;
     int32_t n_lights; light *lights;
     v3 cam_pos; float cam_mat[9]; float background[3];
     int32_t width, height, bucket_size;
@@ -146,7 +149,7 @@ ora_scene *ora_scene_create(const ora_scene_desc *d) {
     ora_scene *s = (ora_scene *)calloc(1, sizeof(*s));
     s->n_meshes = d->n_meshes;
     s->meshes = (mesh_object *)calloc((size_t)d->n_meshes, sizeof(mesh_object));
-    size_t voff = 0, toff = 0;
+    size_t voff = 0, toff = 0, uvoff = 0;
     for (int m = 0; m < d->n_meshes; ++m) {                          /* loader.hpp:149-233 + mesh.hpp:23-44 */
         mesh_object *mo = &s->meshes[m];
         mo->material_idx = d->mesh_material[m];
@@ -161,7 +164,14 @@ ora_scene *ora_scene_create(const ora_scene_desc *d) {
         for (int i = 0; i < mo->ntris; ++i) {
             const uint32_t *ix = &d->indices[(toff + (size_t)i) * 3];
             mo->triangles[i] = make_triangle(mo->vertices[ix[0]], mo->vertices[ix[1]], mo->vertices[ix[2]], ix, (uint32_t)m);
+            memset(mo->triangles[i].uvs, 0, sizeof(mo->triangles[i].uvs));
+            if (d->mesh_has_uvs && d->mesh_has_uvs[m])                       /* loader.hpp:199-207 */
+                for (int k = 0; k < 3; ++k) {
+                    mo->triangles[i].uvs[k * 2] = d->uvs[(uvoff + ix[k]) * 2];
+                    mo->triangles[i].uvs[k * 2 + 1] = d->uvs[(uvoff + ix[k]) * 2 + 1];
+                }
         }
+        if (d->mesh_has_uvs && d->mesh_has_uvs[m]) uvoff += (size_t)mo->nverts;
         mo->box = aabb_empty();
         for (int i = 0; i < mo->ntris; ++i) {                         /* mesh.hpp:27-38 */
             const triangle *t = &mo->triangles[i];
@@ -181,6 +191,15 @@ ora_scene *ora_scene_create(const ora_scene_desc *d) {
         memcpy(s->materials[i].albedo, &d->mat_albedo[i * 3], sizeof(float) * 3);
         s->materials[i].ior = d->mat_ior[i];
         s->materials[i].smooth = d->mat_smooth[i];
+        s->materials[i].texture = d->mat_texture ? d->mat_texture[i] : -1;
+    }
+    s->n_textures = d->n_textures;
+    s->textures = (texture *)calloc((size_t)(d->n_textures ? d->n_textures : 1), sizeof(texture));
+    for (int i = 0; i < d->n_textures; ++i) {
+        s->textures[i].kind = d->tex_kind[i];
+        memcpy(s->textures[i].a, &d->tex_color_a[i * 3], sizeof(float) * 3);
+        memcpy(s->textures[i].b, &d->tex_color_b[i * 3], sizeof(float) * 3);
+        s->textures[i].param = d->tex_param[i];
     }
     s->n_lights = d->n_lights;
     s->lights = (light *)calloc((size_t)(d->n_lights ? d->n_lights : 1), sizeof(light));
@@ -200,7 +219,7 @@ void ora_scene_destroy(ora_scene *s) {
     for (int m = 0; m < s->n_meshes; ++m) {
         free(s->meshes[m].vertices); free(s->meshes[m].vertex_normals); free(s->meshes[m].triangles);
     }
-    free(s->meshes); free(s->materials); free(s->lights); free(s);
+    free(s->meshes); free(s->materials); free(s->textures); free(s->lights); free(s);
 }
 
 void ora_scene_vertex_normals(const ora_scene *s, int mesh, float *out) {
@@ -474,6 +493,7 @@ typedef struct {                                 /* render/hit.hpp:9-21 (uvs omi
     ray3 ray; v3 position, hit_normal, face_normal;
     float distance, u, v, w;
     uint32_t mesh_idx, tri_idx;
+    const float *uvs;                            /* triangle.uvs (6 floats) */
 } hit_rec;
 
 #define ORA_STACK_CAP 256
@@ -536,6 +556,7 @@ static int accel_intersect(const ora_accel *a, const ray3 *ray, int cull, hit_re
     out->face_normal = tr->normal;
     out->distance = closest.t; out->u = u; out->v = v; out->w = w;
     out->mesh_idx = tr->mesh_idx; out->tri_idx = (uint32_t)closest.tri;
+    out->uvs = tr->uvs;
     return 1;
 }
 
@@ -655,6 +676,20 @@ static int is_occluded(const frame_ctx *f, thread_ctx *tc, ray3 ray, float max_t
     return 0;
 }
 
+/* sample(texture_variant, hit, uvs): scene/texture/albedo.hpp:9-11, edge.hpp:12-21, checker.hpp:13-28.
+ * `1. - hit_u - hit_v` has a double literal there: hit_w is computed in double and rounded to F. */
+static col sample_texture(const texture *t, const hit_rec *h) {
+    const col a = {t->a[0], t->a[1], t->a[2]}, b = {t->b[0], t->b[1], t->b[2]};
+    if (t->kind == ORA_TEX_ALBEDO) return a;
+    const float hit_u = h->u, hit_v = h->v;
+    const float hit_w = (float)(1. - hit_u - hit_v);
+    if (t->kind == ORA_TEX_EDGES) return (hit_u < t->param || hit_v < t->param || hit_w < t->param) ? a : b;
+    const float fx = (hit_w * h->uvs[0] + hit_u * h->uvs[2]) + hit_v * h->uvs[4];
+    const float fy = (hit_w * h->uvs[1] + hit_u * h->uvs[3]) + hit_v * h->uvs[5];
+    const int32_t u2 = (int32_t)(fx / t->param), v2 = (int32_t)(fy / t->param);
+    return ((u2 + v2) % 2 == 0) ? a : b;
+}
+
 /* render.hpp:133-308 */
 /* `key` is the RNG key of the ray that produced this hit */
 static col color_hit(const frame_ctx *f, thread_ctx *tc, const hit_rec *hr, int depth, uint32_t key) {
@@ -705,6 +740,21 @@ static col color_hit(const frame_ctx *f, thread_ctx *tc, const hit_rec *hr, int 
             final = cadd(final, cscl((L->intensity / area) * cosine, albedo));
         }
         final = cdiv(final, (float)(f->p.diffuse_rays + 1));                /* :208 */
+        return final;
+    }
+    case ORA_MAT_TEXTURE: {                                                  /* :211-238: light loop, no GI, no division */
+        col final = mkcol(0.f, 0.f, 0.f);
+        for (int li = 0; li < sc->n_lights; ++li) {
+            const light *L = &sc->lights[li];
+            v3 ld = sub3(L->position, P);
+            const float radius = len3(ld);
+            const float area = 4.0f * PI_F * radius * radius;
+            ld = norm3(ld);
+            const float cosine = fmaxstd(0.0f, dot3(ld, m->smooth ? hn : fn));
+            const ray3 sr = mkray(add3(P, scl3(f->p.shadow_bias, ld)), ld);
+            if (is_occluded(f, tc, sr, radius)) continue;
+            final = cadd(final, cscl((L->intensity / area) * cosine, sample_texture(&sc->textures[m->texture], hr)));
+        }
         return final;
     }
     case ORA_MAT_REFLECTIVE: {                                               /* :239-250 */

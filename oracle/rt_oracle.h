@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-enum { ORA_MAT_DIFFUSE = 0, ORA_MAT_REFLECTIVE = 1, ORA_MAT_REFRACTIVE = 2, ORA_MAT_CONSTANT = 3 };
+enum { ORA_MAT_DIFFUSE = 0, ORA_MAT_REFLECTIVE = 1, ORA_MAT_REFRACTIVE = 2, ORA_MAT_CONSTANT = 3, ORA_MAT_TEXTURE = 4 };
+enum { ORA_TEX_ALBEDO = 0, ORA_TEX_EDGES = 1, ORA_TEX_CHECKER = 2 };   /* scene/texture/texture.hpp:13, bitmap unsupported */
 enum { ORA_ACCEL_KD_SIMD = 0, ORA_ACCEL_KD_SCALAR = 1 };
 
 typedef struct ora_scene ora_scene;
@@ -46,6 +47,14 @@ typedef struct {
     const float *mat_albedo;       /* [n_materials][3] */
     const float *mat_ior;          /* [n_materials] */
     const int32_t *mat_smooth;     /* [n_materials] */
+    const int32_t *mat_texture;    /* [n_materials] texture index for ORA_MAT_TEXTURE */
+    const float *uvs;              /* concatenated [.][2] per-vertex uv of the meshes with mesh_has_uvs */
+    const int32_t *mesh_has_uvs;   /* [n_meshes] */
+    int32_t n_textures;
+    const int32_t *tex_kind;       /* [n_textures] ORA_TEX_* */
+    const float *tex_color_a;      /* [n_textures][3] */
+    const float *tex_color_b;      /* [n_textures][3] */
+    const float *tex_param;        /* [n_textures] edge_width / square_size */
     int32_t n_lights;
     const float *light_pos;        /* [n_lights][3] */
     const float *light_intensity;  /* [n_lights] */

@@ -23,13 +23,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librtk_hip.so")
 
 RTK_OK, RTK_ERR_INVALID, RTK_ERR_NO_DEVICE, RTK_ERR_HIP, RTK_ERR_IO, RTK_ERR_PARSE, RTK_ERR_UNSUPPORTED = range(7)
-MAT_DIFFUSE, MAT_REFLECTIVE, MAT_REFRACTIVE, MAT_CONSTANT = 0, 1, 2, 3
+MAT_DIFFUSE, MAT_REFLECTIVE, MAT_REFRACTIVE, MAT_CONSTANT, MAT_TEXTURE = 0, 1, 2, 3, 4
+TEX_ALBEDO, TEX_EDGES, TEX_CHECKER = 0, 1, 2
 TRACE_AUTO, TRACE_LANE, TRACE_WAVE, TRACE_GROUP4, TRACE_GROUP8, TRACE_GROUP2, TRACE_STREAM, TRACE_TWOPASS = 0, 1, 2, 3, 4, 5, 6, 7
 
 # every symbol include/rtk.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "rtk_abi_version", "rtk_last_error", "rtk_device_count",
-    "rtk_scene_create", "rtk_scene_load_crtscene", "rtk_scene_get_info", "rtk_scene_get_arrays",
+    "rtk_scene_create", "rtk_scene_load_crtscene", "rtk_scene_get_info", "rtk_scene_get_arrays", "rtk_scene_get_textures",
     "rtk_scene_vertex_normals", "rtk_scene_destroy",
     "rtk_accel_build", "rtk_accel_tree_info", "rtk_accel_tree_dump", "rtk_accel_destroy",
     "rtk_accel_intersect", "rtk_accel_intersect_device", "rtk_accel_intersect_stats",
@@ -68,6 +69,9 @@ class SceneDesc(C.Structure):
         ("mesh_ntris", C.POINTER(C.c_int32)), ("vertices", C.POINTER(C.c_float)), ("indices", C.POINTER(C.c_uint32)),
         ("n_materials", C.c_int32), ("mat_kind", C.POINTER(C.c_int32)), ("mat_albedo", C.POINTER(C.c_float)),
         ("mat_ior", C.POINTER(C.c_float)), ("mat_smooth", C.POINTER(C.c_int32)),
+        ("mat_texture", C.POINTER(C.c_int32)), ("uvs", C.POINTER(C.c_float)), ("mesh_has_uvs", C.POINTER(C.c_int32)),
+        ("n_textures", C.c_int32), ("tex_kind", C.POINTER(C.c_int32)), ("tex_color_a", C.POINTER(C.c_float)),
+        ("tex_color_b", C.POINTER(C.c_float)), ("tex_param", C.POINTER(C.c_float)),
         ("n_lights", C.c_int32), ("light_pos", C.POINTER(C.c_float)), ("light_intensity", C.POINTER(C.c_float)),
         ("cam_pos", C.c_float * 3), ("cam_mat", C.c_float * 9), ("background", C.c_float * 3),
         ("width", C.c_int32), ("height", C.c_int32), ("bucket_size", C.c_int32),
@@ -76,7 +80,8 @@ class SceneDesc(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("n_meshes", "n_materials", "n_lights", "n_vertices", "n_triangles", "width", "height", "bucket_size")]
+                ("n_meshes", "n_materials", "n_lights", "n_vertices", "n_triangles", "width", "height", "bucket_size",
+                 "n_textures", "n_uv_vertices")]
 
 
 class AccelParams(C.Structure):
@@ -115,6 +120,7 @@ _L.rtk_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(_vp)]
 _L.rtk_scene_load_crtscene.argtypes = [C.c_char_p, C.POINTER(_vp)]
 _L.rtk_scene_get_info.argtypes = [_vp, C.POINTER(SceneInfo)]
 _L.rtk_scene_get_arrays.argtypes = [_vp] * 15
+_L.rtk_scene_get_textures.argtypes = [_vp] * 8
 _L.rtk_scene_vertex_normals.argtypes = [_vp, C.c_int32, _vp]
 _L.rtk_scene_destroy.argtypes = [_vp]
 _L.rtk_scene_destroy.restype = None
@@ -173,8 +179,18 @@ class Scene:
 
     @classmethod
     def from_arrays(cls, mesh_material, mesh_nverts, mesh_ntris, vertices, indices, mat_kind, mat_albedo, mat_ior,
-                    mat_smooth, light_pos, light_intensity, cam_pos, cam_mat, background, width, height, bucket_size=64):
+                    mat_smooth, light_pos, light_intensity, cam_pos, cam_mat, background, width, height, bucket_size=64,
+                    mat_texture=None, uvs=None, mesh_has_uvs=None, tex_kind=None, tex_color_a=None, tex_color_b=None,
+                    tex_param=None):
+        n_tex = 0 if tex_kind is None else len(tex_kind)
         keep = dict(
+            mt=np.ascontiguousarray(mat_texture if mat_texture is not None else np.full(len(mat_kind), -1), np.int32),
+            uv=np.ascontiguousarray(uvs if uvs is not None else np.zeros((0, 2)), np.float32),
+            hu=np.ascontiguousarray(mesh_has_uvs if mesh_has_uvs is not None else np.zeros(len(mesh_material)), np.int32),
+            tk=np.ascontiguousarray(tex_kind if tex_kind is not None else np.zeros(0), np.int32),
+            ta=np.ascontiguousarray(tex_color_a if tex_color_a is not None else np.zeros((n_tex, 3)), np.float32),
+            tb=np.ascontiguousarray(tex_color_b if tex_color_b is not None else np.zeros((n_tex, 3)), np.float32),
+            tp=np.ascontiguousarray(tex_param if tex_param is not None else np.zeros(n_tex), np.float32),
             mm=np.ascontiguousarray(mesh_material, np.int32), nv=np.ascontiguousarray(mesh_nverts, np.int32),
             nt=np.ascontiguousarray(mesh_ntris, np.int32), v=np.ascontiguousarray(vertices, np.float32),
             ix=np.ascontiguousarray(indices, np.uint32), mk=np.ascontiguousarray(mat_kind, np.int32),
@@ -189,6 +205,10 @@ class Scene:
         d.n_materials = len(keep["mk"])
         d.mat_kind, d.mat_albedo = _fp(keep["mk"], C.c_int32), _fp(keep["ma"], C.c_float)
         d.mat_ior, d.mat_smooth = _fp(keep["mi"], C.c_float), _fp(keep["ms"], C.c_int32)
+        d.mat_texture, d.uvs, d.mesh_has_uvs = _fp(keep["mt"], C.c_int32), _fp(keep["uv"], C.c_float), _fp(keep["hu"], C.c_int32)
+        d.n_textures = n_tex
+        d.tex_kind, d.tex_color_a = _fp(keep["tk"], C.c_int32), _fp(keep["ta"], C.c_float)
+        d.tex_color_b, d.tex_param = _fp(keep["tb"], C.c_float), _fp(keep["tp"], C.c_float)
         d.n_lights = len(keep["li"])
         d.light_pos, d.light_intensity = _fp(keep["lp"], C.c_float), _fp(keep["li"], C.c_float)
         d.cam_pos[:] = [float(x) for x in np.asarray(cam_pos, np.float32)]
@@ -211,6 +231,14 @@ class Scene:
             cam_mat=np.zeros(9, np.float32), background=np.zeros(3, np.float32),
         )
         _check(_L.rtk_scene_get_arrays(self._h, *[a.ctypes.data for a in out.values()]))
+        tex = dict(
+            mat_texture=np.zeros(i.n_materials, np.int32), mesh_has_uvs=np.zeros(i.n_meshes, np.int32),
+            uvs=np.zeros((i.n_uv_vertices, 2), np.float32), tex_kind=np.zeros(i.n_textures, np.int32),
+            tex_color_a=np.zeros((i.n_textures, 3), np.float32), tex_color_b=np.zeros((i.n_textures, 3), np.float32),
+            tex_param=np.zeros(i.n_textures, np.float32),
+        )
+        _check(_L.rtk_scene_get_textures(self._h, *[a.ctypes.data for a in tex.values()]))
+        out.update(tex)
         out.update(width=i.width, height=i.height, bucket_size=i.bucket_size)
         return out
 

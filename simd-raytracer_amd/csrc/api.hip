@@ -58,6 +58,8 @@ struct rtk_accel {
     rtk::DevShade *d_shade = nullptr;
     rtk::DevMaterial *d_materials = nullptr;
     rtk::DevLight *d_lights = nullptr;
+    rtk::DevTexture *d_textures = nullptr;
+    rtk::DevTriUv *d_tri_uv = nullptr;
     unsigned long long *d_counters = nullptr;     // 8 x u64 in rtk_counters order + kRayCounterShards ray-count shards
     // streaming-pipeline workspace (grown on demand)
     rtk::dev::StreamWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr, nullptr};
@@ -98,6 +100,10 @@ int ensure_device(rtk_accel *a) {
     if ((rc = upload(a->tree.dev_shade, &a->d_shade)) != RTK_OK) return rc;
     if ((rc = upload(a->scene.materials, &a->d_materials)) != RTK_OK) return rc;
     if ((rc = upload(a->scene.lights, &a->d_lights)) != RTK_OK) return rc;
+    if (!a->scene.textures.empty()) {
+        if ((rc = upload(a->scene.textures, &a->d_textures)) != RTK_OK) return rc;
+        if ((rc = upload(a->tree.dev_tri_uv, &a->d_tri_uv)) != RTK_OK) return rc;
+    }
     RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->d_counters), kCounterWords * sizeof(unsigned long long)));
     RTK_HIP(hipMemset(a->d_counters, 0, kCounterWords * sizeof(unsigned long long)));
     a->on_device = true;
@@ -247,6 +253,9 @@ int rtk_scene_get_info(const rtk_scene *s, rtk_scene_info *info) {
     info->n_vertices = s->n_vertices;
     info->n_triangles = s->n_triangles;
     info->width = s->width; info->height = s->height; info->bucket_size = s->bucket_size;
+    info->n_textures = int32_t(s->textures.size());
+    info->n_uv_vertices = 0;
+    for (const HostMesh &m : s->meshes) info->n_uv_vertices += int32_t(m.uvs.size() / 2);
     return RTK_OK;
 }
 
@@ -280,6 +289,26 @@ int rtk_scene_get_arrays(const rtk_scene *s, int32_t *mesh_material, int32_t *me
     if (cam_pos) std::memcpy(cam_pos, s->cam_pos, sizeof(s->cam_pos));
     if (cam_mat) std::memcpy(cam_mat, s->cam_mat, sizeof(s->cam_mat));
     if (background) std::memcpy(background, s->background, sizeof(s->background));
+    return RTK_OK;
+}
+
+int rtk_scene_get_textures(const rtk_scene *s, int32_t *mat_texture, int32_t *mesh_has_uvs, float *uvs, int32_t *tex_kind,
+                           float *tex_color_a, float *tex_color_b, float *tex_param) {
+    if (!s) return fail(RTK_ERR_INVALID, "null scene");
+    for (size_t i = 0; i < s->materials.size(); ++i) if (mat_texture) mat_texture[i] = s->materials[i].texture;
+    size_t uo = 0;
+    for (size_t m = 0; m < s->meshes.size(); ++m) {
+        const HostMesh &hm = s->meshes[m];
+        if (mesh_has_uvs) mesh_has_uvs[m] = hm.uvs.empty() ? 0 : 1;
+        if (uvs && !hm.uvs.empty()) std::memcpy(uvs + uo, hm.uvs.data(), hm.uvs.size() * sizeof(float));
+        uo += hm.uvs.size();
+    }
+    for (size_t i = 0; i < s->textures.size(); ++i) {
+        if (tex_kind) tex_kind[i] = s->textures[i].kind;
+        if (tex_color_a) std::memcpy(tex_color_a + i * 3, s->textures[i].a, 3 * sizeof(float));
+        if (tex_color_b) std::memcpy(tex_color_b + i * 3, s->textures[i].b, 3 * sizeof(float));
+        if (tex_param) tex_param[i] = s->textures[i].param;
+    }
     return RTK_OK;
 }
 
@@ -355,6 +384,7 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipSetDevice(a->device);
         (void)hipFree(a->d_nodes); (void)hipFree(a->d_tris); (void)hipFree(a->d_tri_ids); (void)hipFree(a->d_shade);
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
+        (void)hipFree(a->d_textures); (void)hipFree(a->d_tri_uv);
         (void)hipFree(a->ws.rays); (void)hipFree(a->ws.nodes); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
         (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
         (void)hipFree(a->ws.node_bins); (void)hipFree(a->ws.hit_bins); (void)hipFree(a->ws.node_order); (void)hipFree(a->ws.hit_order);
@@ -446,6 +476,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     std::memset(&A, 0, sizeof(A));
     A.tree = tree_view(a);
     A.materials = a->d_materials; A.lights = a->d_lights;
+    A.textures = a->d_textures; A.tri_uv = a->d_tri_uv;
     A.n_lights = int(a->scene.lights.size());
     A.has_refractive = a->has_refractive ? 1 : 0;
     std::memcpy(A.cam_pos, a->scene.cam_pos, sizeof(A.cam_pos));

@@ -64,6 +64,19 @@ static __device__ __noinline__ void det_sincos(float angle, float &s, float &c) 
     c = (float)cv;
 }
 
+// sample(texture, hit, uvs) for the procedural textures (scene/texture/albedo.hpp:9-11, edge.hpp:12-21, checker.hpp:13-28).
+// hit_w is evaluated in double there (`1. - hit_u - hit_v` with a double literal) and rounded to float.
+__device__ __forceinline__ V3 sample_texture(const DevTexture *T, const DevTriUv *uv, const float u, const float v) {
+    const V3 a = mk(T->a[0], T->a[1], T->a[2]), b = mk(T->b[0], T->b[1], T->b[2]);
+    if (T->kind == RTK_TEX_ALBEDO) return a;
+    const float w = (float)((1.0 - (double)u) - (double)v);
+    if (T->kind == RTK_TEX_EDGES) return (u < T->param || v < T->param || w < T->param) ? a : b;
+    const float fx = (w * uv->uv[0] + u * uv->uv[2]) + v * uv->uv[4];          // hit_w * uvs.x + hit_u * uvs.y + hit_v * uvs.z
+    const float fy = (w * uv->uv[1] + u * uv->uv[3]) + v * uv->uv[5];
+    const int u2 = (int)(fx / T->param), v2 = (int)(fy / T->param);
+    return ((u2 + v2) % 2 == 0) ? a : b;
+}
+
 // Camera ray of pixel (px, py) (render.hpp:35-62); `key` is the sample's root key (draws 0 and 1 jitter the sample).
 __device__ __forceinline__ Ray camera_ray(const RenderArgs &A, const uint32_t px, const uint32_t py, const uint32_t key) {
     float rx = (float)px, ry = (float)py;

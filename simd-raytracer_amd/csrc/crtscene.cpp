@@ -198,21 +198,64 @@ int scene_from_crtscene(const char *path, rtk_scene &out, std::string &err) {
             dl.intensity = f32(need(l.get(), "intensity", JValue::Number, "light"), "light.intensity");
             out.lights.push_back(dl);
         }
+        // load_texture, loader.hpp:78-106; scene.textures is keyed by name there (loader.hpp:249-253), by index here
+        out.textures.clear();
+        std::vector<std::string> texture_names;
+        std::vector<bool> texture_is_bitmap;
+        if (const JValue *texs = root.get("textures")) {
+            if (texs->kind == JValue::Array) for (const JPtr &t : texs->arr) {
+                DevTexture dt;
+                std::memset(&dt, 0, sizeof(dt));
+                const std::string &type = need(t.get(), "type", JValue::String, "texture").str;
+                bool bitmap = false;
+                if (type == "albedo") {
+                    dt.kind = RTK_TEX_ALBEDO;
+                    floats(need(t.get(), "albedo", JValue::Array, "texture"), 3, dt.a, "texture.albedo");
+                } else if (type == "edges") {
+                    dt.kind = RTK_TEX_EDGES;
+                    floats(need(t.get(), "edge_color", JValue::Array, "texture"), 3, dt.a, "texture.edge_color");
+                    floats(need(t.get(), "inner_color", JValue::Array, "texture"), 3, dt.b, "texture.inner_color");
+                    dt.param = f32(need(t.get(), "edge_width", JValue::Number, "texture"), "texture.edge_width");
+                } else if (type == "checker") {
+                    dt.kind = RTK_TEX_CHECKER;
+                    floats(need(t.get(), "color_A", JValue::Array, "texture"), 3, dt.a, "texture.color_A");
+                    floats(need(t.get(), "color_B", JValue::Array, "texture"), 3, dt.b, "texture.color_B");
+                    dt.param = f32(need(t.get(), "square_size", JValue::Number, "texture"), "texture.square_size");
+                } else if (type == "bitmap") {
+                    bitmap = true;                       // needs an image decoder: only an error if a material uses it
+                } else {
+                    throw Fail{RTK_ERR_INVALID, "texture type unknown"};
+                }
+                texture_names.push_back(need(t.get(), "name", JValue::String, "texture").str);
+                texture_is_bitmap.push_back(bitmap);
+                out.textures.push_back(dt);
+            }
+        }
         // load_material, loader.hpp:108-147
         out.materials.clear();
         for (const JPtr &m : need(&root, "materials", JValue::Array, "scene").arr) {
             DevMaterial dm;
             std::memset(&dm, 0, sizeof(dm));
             dm.ior = 1.0f;
+            dm.texture = -1;
             const std::string &type = need(m.get(), "type", JValue::String, "material").str;
             if (type == "diffuse") {
                 const JValue *alb = m->get("albedo");
                 if (!alb) throw Fail{RTK_ERR_PARSE, "missing key 'albedo' in material"};
-                if (alb->kind == JValue::String)
-                    throw Fail{RTK_ERR_UNSUPPORTED, "texture materials are outside the accelerated path"};
-                if (alb->kind != JValue::Array) throw Fail{RTK_ERR_INVALID, "albedo neither array nor string"};
-                dm.kind = RTK_MAT_DIFFUSE;
-                floats(*alb, 3, dm.albedo, "material.albedo");
+                if (alb->kind == JValue::String) {                    // texture_material, loader.hpp:120-125
+                    dm.kind = RTK_MAT_TEXTURE;
+                    dm.texture = -1;
+                    for (size_t ti = 0; ti < texture_names.size(); ++ti)
+                        if (texture_names[ti] == alb->str) dm.texture = static_cast<int32_t>(ti);
+                    if (dm.texture < 0) throw Fail{RTK_ERR_INVALID, "material refers to unknown texture '" + alb->str + "'"};
+                    if (texture_is_bitmap[static_cast<size_t>(dm.texture)])
+                        throw Fail{RTK_ERR_UNSUPPORTED, "bitmap textures need an image decoder and are outside the accelerated path"};
+                } else if (alb->kind == JValue::Array) {
+                    dm.kind = RTK_MAT_DIFFUSE;
+                    floats(*alb, 3, dm.albedo, "material.albedo");
+                } else {
+                    throw Fail{RTK_ERR_INVALID, "albedo neither array nor string"};
+                }
             } else if (type == "reflective") {
                 dm.kind = RTK_MAT_REFLECTIVE;
                 floats(need(m.get(), "albedo", JValue::Array, "material"), 3, dm.albedo, "material.albedo");
@@ -241,6 +284,21 @@ int scene_from_crtscene(const char *path, rtk_scene &out, std::string &err) {
             mesh.vertices.resize(vs.arr.size() / 3);
             for (size_t i = 0; i < mesh.vertices.size(); ++i)
                 mesh.vertices[i] = {f32(*vs.arr[i * 3], "vertices"), f32(*vs.arr[i * 3 + 1], "vertices"), f32(*vs.arr[i * 3 + 2], "vertices")};
+            if (const JValue *uv = o->get("uvs")) {                      // loader.hpp:173-192: (u, v, ignored) triples
+                if (uv->kind == JValue::Array) {
+                    if (uv->arr.size() % 3) throw Fail{RTK_ERR_INVALID, "uv coordinates not multiple of 3"};
+                    mesh.uvs.resize(uv->arr.size() / 3 * 2);
+                    for (size_t i = 0; i < uv->arr.size() / 3; ++i) {
+                        mesh.uvs[i * 2] = f32(*uv->arr[i * 3], "uvs");
+                        mesh.uvs[i * 2 + 1] = f32(*uv->arr[i * 3 + 1], "uvs");
+                    }
+                    if (mesh.uvs.size() != mesh.vertices.size() * 2) {
+                        if (mesh.uvs.empty()) mesh.uvs.clear();
+                        else if (mesh.uvs.size() < mesh.vertices.size() * 2) throw Fail{RTK_ERR_INVALID, "fewer uvs than vertices"};
+                        else mesh.uvs.resize(mesh.vertices.size() * 2);
+                    }
+                }
+            }
             const JValue &ts = need(o.get(), "triangles", JValue::Array, "object");
             if (ts.arr.size() % 3) throw Fail{RTK_ERR_INVALID, "triangle indices not multiple of 3"};
             mesh.indices.resize(ts.arr.size());

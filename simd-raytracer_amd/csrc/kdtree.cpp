@@ -169,6 +169,18 @@ int build_tree(const rtk_scene &scene, int max_depth, int max_leaf, HostTree &ou
         s.mesh = tr.mesh;
         s.material = uint32_t(m.material);
     }
+    if (!scene.textures.empty()) {                                       // triangle::uvs, loader.hpp:199-207
+        out.dev_tri_uv.resize(out.triangles.size());
+        for (size_t i = 0; i < out.triangles.size(); ++i) {
+            const HostTriangle &tr = out.triangles[i];
+            const HostMesh &m = scene.meshes[tr.mesh];
+            DevTriUv &u = out.dev_tri_uv[i];
+            for (int k = 0; k < 3; ++k) {
+                u.uv[k * 2] = m.uvs.empty() ? 0.0f : m.uvs[size_t(tr.vi[k]) * 2];
+                u.uv[k * 2 + 1] = m.uvs.empty() ? 0.0f : m.uvs[size_t(tr.vi[k]) * 2 + 1];
+            }
+        }
+    }
     if (out.dev_nodes.size() != out.nodes.size() || out.dev_tris.size() != out.leaf_refs.size()) {
         err = "internal: flattening lost nodes"; return RTK_ERR_INVALID;
     }

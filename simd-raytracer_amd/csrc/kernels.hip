@@ -150,6 +150,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (
     V3 P = black, hn = black, fn = black, din = black, ncos = black, acc = black, albedo = black;
     uint32_t hit_tri = 0, hit_mat = 0;
     float shadow_max_t = 0.f, contrib = 0.f;
+    bool lit_textured = false;
     Frame frames[FORKS ? kMaxRayDepth : 1];
     int fsp = 0;
     Stats st = {0, 0, 0, 0, 0, 0};
@@ -222,11 +223,12 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (
                         cull = false; depth += 1; pend = PEND_CHILD_BLACK;
                         state = ST_TRACE;
                     }
-                } else {                                                                        // diffuse, :148-209
-                    albedo = mk(mat->albedo[0], mat->albedo[1], mat->albedo[2]);
+                } else {                                                                        // diffuse :148-209, texture :211-238
+                    lit_textured = (kind == RTK_MAT_TEXTURE);          // light loop only: no GI rays, no final division
+                    if (!lit_textured) albedo = mk(mat->albedo[0], mat->albedo[1], mat->albedo[2]);
                     ncos = mat->smooth ? hn : fn;
                     acc = black;
-                    if (FORKS && A.diffuse_rays > 0) {
+                    if (FORKS && A.diffuse_rays > 0 && !lit_textured) {
                         Frame &f = frames[fsp++];
                         f.a[0] = P.x; f.a[1] = P.y; f.a[2] = P.z;
                         f.a[3] = din.x; f.a[4] = din.y; f.a[5] = din.z;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (
             } else if (state == ST_LIGHT) {                                 // light loop, render.hpp:184-208
                 if (light_k == A.n_lights) {
                     const float div = (float)(A.diffuse_rays + 1);
-                    ret = mk(acc.x / div, acc.y / div, acc.z / div);
+                    ret = lit_textured ? acc : mk(acc.x / div, acc.y / div, acc.z / div);
                     state = ST_RETURN;
                     continue;
                 }
@@ -328,6 +330,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (
                         const DevMaterial *mat = A.materials + hit_mat;
                         albedo = mk(mat->albedo[0], mat->albedo[1], mat->albedo[2]);
                         ncos = mat->smooth ? hn : fn;
+                        lit_textured = false;
                         depth = fdepth;
                         fsp -= 1;
                         light_k = 0;
@@ -385,6 +388,8 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (
                 P = ray.o + (cand.t * ray.d);                                // kd_tree_simd.hpp:254
                 hn = s.hit_normal; fn = s.face_normal; din = ray.d;
                 hit_tri = s.tri; hit_mat = s.material;
+                if (A.tri_uv != nullptr && A.materials[hit_mat].kind == RTK_MAT_TEXTURE)      // texture_material: colour of this hit
+                    albedo = sample_texture(A.textures + A.materials[hit_mat].texture, A.tri_uv + hit_tri, cand.u, cand.v);
                 state = ST_SHADE;
             }
         }

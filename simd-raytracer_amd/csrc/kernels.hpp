@@ -33,6 +33,8 @@ struct IntersectArgs {
 struct RenderArgs {
     TreeView tree;
     const DevMaterial *materials;
+    const DevTexture *textures;       // procedural textures (null / unused when the scene has none)
+    const DevTriUv *tri_uv;           // per-triangle uvs, only when the scene has textures
     const DevLight *lights;
     int n_lights;
     int has_refractive;

@@ -52,7 +52,20 @@ struct DevMaterial {  // scene/material/*.hpp flattened
     int32_t smooth;
     float albedo[3];
     float ior;
-    uint32_t pad[2];
+    int32_t texture;      // RTK_MAT_TEXTURE: index into the texture table
+    uint32_t pad;
+};
+
+struct DevTexture {   // scene/texture/{albedo,edge,checker}.hpp flattened
+    int32_t kind;
+    float a[3];           // albedo / edge_color / color_a
+    float b[3];           // - / inner_color / color_b
+    float param;          // - / edge_width / square_size
+};
+static_assert(sizeof(DevTexture) == 32, "DevTexture must be 32 bytes");
+
+struct DevTriUv {     // triangle::uvs (scene/primitive/triangle.hpp:18): uv of vertex_indices[0], [1], [2]
+    float uv[6];
 };
 static_assert(sizeof(DevMaterial) == 32, "DevMaterial must be 32 bytes");
 
@@ -77,6 +90,7 @@ struct HostMesh {       // scene/object/mesh.hpp:15-44
     int32_t material = 0;
     std::vector<Vec3> vertices;
     std::vector<Vec3> vertex_normals;
+    std::vector<float> uvs;          // [nverts*2] or empty (then every triangle's uvs are zero, loader.hpp:199-207)
     std::vector<uint32_t> indices;   // [ntris*3]
     Box box;
 };
@@ -93,6 +107,7 @@ struct HostNode {       // kd_tree_simd.hpp:75-84, reference (creation) order
 struct rtk_scene {
     std::vector<rtk::HostMesh> meshes;
     std::vector<rtk::DevMaterial> materials;
+    std::vector<rtk::DevTexture> textures;
     std::vector<rtk::DevLight> lights;
     float cam_pos[3];
     float cam_mat[9];
@@ -112,6 +127,7 @@ struct HostTree {
     std::vector<DevTri> dev_tris;
     std::vector<uint32_t> dev_tri_ids;         // leaf-ref -> global triangle index
     std::vector<DevShade> dev_shade;           // per global triangle
+    std::vector<DevTriUv> dev_tri_uv;          // per global triangle (only filled when the scene has textures)
     int32_t depth = 0;
 };
 

@@ -63,7 +63,7 @@ int scene_from_desc(const rtk_scene_desc &d, rtk_scene &out, std::string &err) {
     if (d.n_meshes < 0 || d.n_materials < 0 || d.n_lights < 0) { err = "negative count in rtk_scene_desc"; return RTK_ERR_INVALID; }
     if (d.n_meshes > 0 && (!d.mesh_material || !d.mesh_nverts || !d.mesh_ntris)) { err = "null mesh arrays"; return RTK_ERR_INVALID; }
     out.meshes.clear();
-    size_t voff = 0, toff = 0;
+    size_t voff = 0, toff = 0, uvoff = 0;
     for (int32_t mi = 0; mi < d.n_meshes; ++mi) {
         const int32_t nv = d.mesh_nverts[mi], nt = d.mesh_ntris[mi];
         if (nv < 0 || nt < 0) { err = "negative mesh size"; return RTK_ERR_INVALID; }
@@ -77,6 +77,11 @@ int scene_from_desc(const rtk_scene_desc &d, rtk_scene &out, std::string &err) {
             m.vertices[static_cast<size_t>(i)] = {p[0], p[1], p[2]};
         }
         m.indices.assign(d.indices + toff * 3, d.indices + (toff + static_cast<size_t>(nt)) * 3);
+        if (d.mesh_has_uvs && d.mesh_has_uvs[mi] != 0) {
+            if (!d.uvs) { err = "mesh_has_uvs set but uvs is null"; return RTK_ERR_INVALID; }
+            m.uvs.assign(d.uvs + uvoff * 2, d.uvs + (uvoff + static_cast<size_t>(nv)) * 2);
+            uvoff += static_cast<size_t>(nv);
+        }
         const int rc = finish_mesh(m, err);
         if (rc != RTK_OK) return rc;
         out.meshes.push_back(std::move(m));
@@ -90,10 +95,26 @@ int scene_from_desc(const rtk_scene_desc &d, rtk_scene &out, std::string &err) {
         DevMaterial &m = out.materials[static_cast<size_t>(i)];
         std::memset(&m, 0, sizeof(m));
         m.kind = d.mat_kind[i];
-        if (m.kind < RTK_MAT_DIFFUSE || m.kind > RTK_MAT_CONSTANT) { err = "material type unknown"; return RTK_ERR_UNSUPPORTED; }
+        if (m.kind < RTK_MAT_DIFFUSE || m.kind > RTK_MAT_TEXTURE) { err = "material type unknown"; return RTK_ERR_INVALID; }
+        m.texture = -1;
+        if (m.kind == RTK_MAT_TEXTURE) {
+            m.texture = d.mat_texture ? d.mat_texture[i] : -1;
+            if (m.texture < 0 || m.texture >= d.n_textures) { err = "texture material refers to a texture that does not exist"; return RTK_ERR_INVALID; }
+        }
         m.smooth = d.mat_smooth ? d.mat_smooth[i] : 0;
         if (d.mat_albedo) std::memcpy(m.albedo, d.mat_albedo + i * 3, sizeof(float) * 3);
         m.ior = d.mat_ior ? d.mat_ior[i] : 1.0f;
+    }
+    if (d.n_textures < 0) { err = "negative texture count"; return RTK_ERR_INVALID; }
+    out.textures.resize(static_cast<size_t>(d.n_textures));
+    for (int32_t i = 0; i < d.n_textures; ++i) {
+        DevTexture &t = out.textures[static_cast<size_t>(i)];
+        std::memset(&t, 0, sizeof(t));
+        t.kind = d.tex_kind[i];
+        if (t.kind < RTK_TEX_ALBEDO || t.kind > RTK_TEX_CHECKER) { err = "texture type unknown"; return RTK_ERR_INVALID; }
+        if (d.tex_color_a) std::memcpy(t.a, d.tex_color_a + i * 3, sizeof(float) * 3);
+        if (d.tex_color_b) std::memcpy(t.b, d.tex_color_b + i * 3, sizeof(float) * 3);
+        t.param = d.tex_param ? d.tex_param[i] : 0.0f;
     }
     out.lights.resize(static_cast<size_t>(d.n_lights));
     for (int32_t i = 0; i < d.n_lights; ++i) {

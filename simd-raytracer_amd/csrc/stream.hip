@@ -269,6 +269,10 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
                         c1o = ro; c1d = rd;                                                     // child 1: reflection
                         kind = NODE_REFR; nchild = 2u;
                     }
+                } else if (mkind == RTK_MAT_TEXTURE) {                                          // :211-238
+                    ncos = m->smooth ? hn : s.face_normal;
+                    value = sample_texture(A.textures + m->texture, A.tri_uv + s.tri, c.u, c.v);
+                    kind = NODE_TEX; push_hit = true;
                 } else {                                                                        // diffuse, :148-209
                     ncos = m->smooth ? hn : s.face_normal;
                     kind = NODE_DIFF; nchild = (uint32_t)A.diffuse_rays; push_hit = true;
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
                 store_ray(S.ws.rays + first_child + 1u, c1o, c1d, node, pix, child_key(key, 1u), kRayValid);
                 if (S.bin_children) atomicAdd(S.ws.node_bins + ray_sort_key(S, c1o, c1d), 1u);
             }
-        } else if (kind == NODE_DIFF) {
+        } else if (kind == NODE_DIFF || kind == NODE_TEX) {
             aux = hit_base + hit_slot;
             float4 *q = reinterpret_cast<float4 *>(S.ws.hits + aux);
             q[0] = make_float4(P.x, P.y, P.z, __uint_as_float(node));
@@ -486,6 +490,13 @@ __global__ __launch_bounds__(256) void k_combine(StreamArgs S) {
             const float fresnel = __uint_as_float(aux);
             const V3 refr = mk(c0->value[0], c0->value[1], c0->value[2]), refl = mk(c1->value[0], c1->value[1], c1->value[2]);
             v = (fresnel * refl) + ((1.0f - fresnel) * refr);
+        } else if (kind == NODE_TEX) {                                         // :211-238
+            V3 acc = mk(0.f, 0.f, 0.f);
+            for (uint32_t k = 0; k < n_lights; ++k) {
+                const float2 cv = S.ws.contrib[(size_t)aux * n_lights + k];
+                if (cv.y != 0.0f) acc = acc + (cv.x * v);                      // v still holds the sampled texture colour
+            }
+            v = acc;
         } else if (kind == NODE_DIFF) {                                        // :151-208
             const HitRec *h = S.ws.hits + aux;
             const DevMaterial *m = A.materials + h->mat;

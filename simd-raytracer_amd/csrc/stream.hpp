@@ -33,7 +33,8 @@ enum : uint32_t {
     NODE_LEAF = 0,          // value is final: miss colour, depth limit, constant material
     NODE_PASS = 1,          // reflective / total internal reflection: the value of the single child
     NODE_REFR = 2,          // refractive: fresnel * child[1] + (1 - fresnel) * child[0]   (child 0 = refraction ray)
-    NODE_DIFF = 3           // diffuse: (sum of GI children, then unoccluded lights in order) / (diffuse_rays + 1)
+    NODE_DIFF = 3,          // diffuse: (sum of GI children, then unoccluded lights in order) / (diffuse_rays + 1)
+    NODE_TEX = 4            // texture material: unoccluded lights in order times the sampled colour kept in `value`
 };
 
 struct HitRec {             // 32 B: a diffuse shading point waiting for its light loop

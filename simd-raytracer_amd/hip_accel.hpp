@@ -39,14 +39,40 @@ struct hip_accel {
         : scene_ptr(std::move(scene_ptr_)) {
         const scene<F> &sc = *scene_ptr;
         // flatten scene<F> exactly as parse_scene_file laid it out (io/json/loader.hpp:235-265)
-        std::vector<int32_t> mesh_material, mesh_nverts, mesh_ntris, mat_kind, mat_smooth;
-        std::vector<float> vertices, mat_albedo, mat_ior, light_pos, light_intensity;
+        std::vector<int32_t> mesh_material, mesh_nverts, mesh_ntris, mat_kind, mat_smooth, mat_texture, mesh_has_uvs, tex_kind;
+        std::vector<float> vertices, mat_albedo, mat_ior, light_pos, light_intensity, uvs, tex_a, tex_b, tex_param;
         std::vector<uint32_t> indices;
+        // scene.textures is keyed by name (scene/scene.hpp:18); the C-ABI refers to textures by index
+        std::vector<std::string> texture_names;
+        for (const auto &[name, tv] : sc.textures) {
+            float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f}, prm = 0.f;
+            int kind = -1;
+            std::visit([&](const auto &t) {
+                using T = std::decay_t<decltype(t)>;
+                if constexpr (std::is_same_v<T, albedo_texture<F>>) { kind = RTK_TEX_ALBEDO; a[0] = t.albedo.red; a[1] = t.albedo.green; a[2] = t.albedo.blue; }
+                else if constexpr (std::is_same_v<T, edge_texture<F>>) {
+                    kind = RTK_TEX_EDGES; prm = t.edge_width;
+                    a[0] = t.edge_color.red; a[1] = t.edge_color.green; a[2] = t.edge_color.blue;
+                    b[0] = t.inner_color.red; b[1] = t.inner_color.green; b[2] = t.inner_color.blue;
+                } else if constexpr (std::is_same_v<T, checker_texture<F>>) {
+                    kind = RTK_TEX_CHECKER; prm = t.square_size;
+                    a[0] = t.color_a.red; a[1] = t.color_a.green; a[2] = t.color_a.blue;
+                    b[0] = t.color_b.red; b[1] = t.color_b.green; b[2] = t.color_b.blue;
+                }
+            }, tv);
+            if (kind < 0) continue;                       // bitmap textures: rejected below if a material uses one
+            texture_names.push_back(name);
+            tex_kind.push_back(kind); tex_param.push_back(prm);
+            tex_a.insert(tex_a.end(), a, a + 3); tex_b.insert(tex_b.end(), b, b + 3);
+        }
         for (const auto &mesh : sc.meshes) {
             mesh_material.push_back(static_cast<int32_t>(mesh.material_idx));
             mesh_nverts.push_back(static_cast<int32_t>(mesh.vertices.size()));
             mesh_ntris.push_back(static_cast<int32_t>(mesh.triangles.size()));
             for (const auto &v : mesh.vertices) { vertices.push_back(v.x); vertices.push_back(v.y); vertices.push_back(v.z); }
+            const bool has_uvs = mesh.uvs.size() >= mesh.vertices.size() && !mesh.uvs.empty();
+            mesh_has_uvs.push_back(has_uvs ? 1 : 0);
+            if (has_uvs) for (std::size_t i = 0; i < mesh.vertices.size(); ++i) { uvs.push_back(mesh.uvs[i].x); uvs.push_back(mesh.uvs[i].y); }
             for (const auto &t : mesh.triangles)
                 for (int k = 0; k < 3; ++k) indices.push_back(static_cast<uint32_t>(t.vertex_indices[k]));
             first_triangle_.push_back(n_triangles_);
@@ -55,7 +81,7 @@ struct hip_accel {
         for (const auto &mv : sc.materials) {
             float albedo[3] = {0.f, 0.f, 0.f};
             float ior = 1.f;
-            int kind = RTK_MAT_DIFFUSE, smooth = 0;
+            int kind = RTK_MAT_DIFFUSE, smooth = 0, texture = -1;
             std::visit([&](const auto &m) {
                 using M = std::decay_t<decltype(m)>;
                 smooth = m.smooth_shading ? 1 : 0;
@@ -63,10 +89,14 @@ struct hip_accel {
                 else if constexpr (std::is_same_v<M, reflective_material<F>>) kind = RTK_MAT_REFLECTIVE;
                 else if constexpr (std::is_same_v<M, refractive_material<F>>) { kind = RTK_MAT_REFRACTIVE; ior = m.ior; }
                 else if constexpr (std::is_same_v<M, constant_material<F>>) kind = RTK_MAT_CONSTANT;
-                else throw std::invalid_argument("hip_accel: texture materials are outside the accelerated path");
+                else {                                    // texture_material (scene/material/texture.hpp)
+                    kind = RTK_MAT_TEXTURE;
+                    for (std::size_t ti = 0; ti < texture_names.size(); ++ti) if (texture_names[ti] == m.texture) texture = static_cast<int>(ti);
+                    if (texture < 0) throw std::invalid_argument("hip_accel: material uses a bitmap or unknown texture '" + m.texture + "'");
+                }
                 if constexpr (requires { m.albedo; }) { albedo[0] = m.albedo.red; albedo[1] = m.albedo.green; albedo[2] = m.albedo.blue; }
             }, mv);
-            mat_kind.push_back(kind); mat_smooth.push_back(smooth); mat_ior.push_back(ior);
+            mat_kind.push_back(kind); mat_smooth.push_back(smooth); mat_ior.push_back(ior); mat_texture.push_back(texture);
             mat_albedo.insert(mat_albedo.end(), albedo, albedo + 3);
         }
         for (const auto &l : sc.lights) {
@@ -79,6 +109,9 @@ struct hip_accel {
         d.vertices = vertices.data(); d.indices = indices.data();
         d.n_materials = static_cast<int32_t>(mat_kind.size());
         d.mat_kind = mat_kind.data(); d.mat_albedo = mat_albedo.data(); d.mat_ior = mat_ior.data(); d.mat_smooth = mat_smooth.data();
+        d.mat_texture = mat_texture.data(); d.uvs = uvs.data(); d.mesh_has_uvs = mesh_has_uvs.data();
+        d.n_textures = static_cast<int32_t>(tex_kind.size());
+        d.tex_kind = tex_kind.data(); d.tex_color_a = tex_a.data(); d.tex_color_b = tex_b.data(); d.tex_param = tex_param.data();
         d.n_lights = static_cast<int32_t>(light_intensity.size());
         d.light_pos = light_pos.data(); d.light_intensity = light_intensity.data();
         d.cam_pos[0] = sc.viewpoint.position.x; d.cam_pos[1] = sc.viewpoint.position.y; d.cam_pos[2] = sc.viewpoint.position.z;

@@ -2,6 +2,7 @@
 #pragma once
 #include <array>
 #include <string>
+#include <unordered_map>
 #include <variant>
 #include <vector>
 #include <raytracer/core/math/ray3.hpp>
@@ -14,6 +15,11 @@ template <typename F> struct constant_material { color<F> albedo; bool smooth_sh
 template <typename F> struct texture_material { std::string texture; bool smooth_shading; };
 template <typename F> using material_variant = std::variant<diffuse_material<F>, reflective_material<F>, refractive_material<F>,
                                                             constant_material<F>, texture_material<F>>;
+template <typename F> struct albedo_texture { color<F> albedo; };
+template <typename F> struct edge_texture { color<F> edge_color, inner_color; F edge_width; };
+template <typename F> struct checker_texture { color<F> color_a, color_b; F square_size; };
+template <typename F> struct bitmap_texture { std::string file_path; };
+template <typename F> using texture_variant = std::variant<albedo_texture<F>, edge_texture<F>, checker_texture<F>, bitmap_texture<F>>;
 template <typename F> struct triangle {
     vec3<F> v0, v1, v2, e1, e2, normal;
     std::array<std::size_t, 3> vertex_indices;
@@ -23,6 +29,7 @@ template <typename F> struct triangle {
 template <typename F> struct mesh_object {
     std::size_t material_idx;
     std::vector<vec3<F>> vertices;
+    std::vector<vec2<F>> uvs;
     std::vector<triangle<F>> triangles;
 };
 template <typename F> struct light { vec3<F> position; F intensity; };
@@ -32,6 +39,7 @@ template <typename F> struct scene {
     settings<F> config;
     camera<F> viewpoint;
     std::vector<light<F>> lights;
+    std::unordered_map<std::string, texture_variant<F>> textures;
     std::vector<material_variant<F>> materials;
     std::vector<mesh_object<F>> meshes;
 };

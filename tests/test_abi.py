@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(rtk):
 
 
 def test_abi_version_and_struct_sizes(rtk):
-    assert rtk.abi_version() == 1
+    assert rtk.abi_version() == 2
     assert rtk.RAY_DTYPE.itemsize == 24
     assert rtk.HIT_DTYPE.itemsize == 32
     assert ctypes.sizeof(rtk.Counters) == 64

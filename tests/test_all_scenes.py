@@ -10,7 +10,9 @@ import pytest
 from conftest import SCENES
 
 ALL = sorted(glob.glob(os.path.join(SCENES, "*", "*.crtscene")))
-LOADABLE = [p for p in ALL if not p.endswith(("hw08/scene0.crtscene", "hw15/scene0.crtscene"))]
+NO_MATERIALS = ("hw08/scene0.crtscene", "hw15/scene0.crtscene")            # the reference's loader throws on these
+BITMAP = ("hw12/scene3.crtscene", "hw12/scene4.crtscene")                  # use the JPEG texture: needs an image decoder
+LOADABLE = [p for p in ALL if not p.endswith(NO_MATERIALS + BITMAP)]
 IDS = [os.path.relpath(p, SCENES)[:-len(".crtscene")] for p in LOADABLE]
 
 
@@ -20,10 +22,10 @@ def _bits(a):
 
 
 def test_scene_set_is_complete():
-    assert len(LOADABLE) == 19
+    assert len(LOADABLE) == 22 and len(ALL) == 26
 
 
-@pytest.mark.parametrize("path", [p for p in ALL if p not in LOADABLE], ids=lambda p: os.path.basename(os.path.dirname(p)) + "/" + os.path.basename(p))
+@pytest.mark.parametrize("path", [p for p in ALL if p.endswith(NO_MATERIALS)], ids=lambda p: os.path.basename(os.path.dirname(p)) + "/" + os.path.basename(p))
 def test_scenes_the_reference_loader_rejects_are_rejected(rtk, path):
     """hw08/scene0 and hw15/scene0 have no "materials": the reference throws in load_mesh (loader.hpp:151 / :253);
     the C-ABI reports RTK_ERR_PARSE instead of inventing a material."""
@@ -32,13 +34,23 @@ def test_scenes_the_reference_loader_rejects_are_rejected(rtk, path):
     assert e.value.code == rtk.RTK_ERR_PARSE
 
 
+@pytest.mark.parametrize("path", [p for p in ALL if p.endswith(BITMAP)], ids=lambda p: os.path.basename(os.path.dirname(p)) + "/" + os.path.basename(p))
+def test_bitmap_textured_scenes_are_refused_not_misrendered(rtk, path):
+    """bitmap_texture decodes a JPEG through stb_image (scene/texture/bitmap.hpp:11-37); there is no decoder here, so a
+    material that uses one is RTK_ERR_UNSUPPORTED.  A bitmap texture that no material uses is fine (hw12/scene0-2)."""
+    with pytest.raises(rtk.RtkError) as e:
+        rtk.parse_scene_file(path)
+    assert e.value.code == rtk.RTK_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("path", LOADABLE, ids=IDS)
 def test_host_side_matches_oracle(rtk, ora, path):
     sc = rtk.parse_scene_file(path)
     flat = ora.load_crtscene(path)
     arr = sc.arrays()
     for k in ("mesh_material", "mesh_nverts", "mesh_ntris", "vertices", "indices", "mat_kind", "mat_albedo", "mat_ior",
-              "mat_smooth", "light_pos", "light_intensity", "cam_pos", "cam_mat", "background"):
+              "mat_smooth", "light_pos", "light_intensity", "cam_pos", "cam_mat", "background", "mat_texture", "mesh_has_uvs",
+              "uvs", "tex_kind", "tex_color_a", "tex_color_b", "tex_param"):
         assert np.array_equal(_bits(arr[k]), _bits(getattr(flat, k))), k
     box, link, refs = rtk.KdTreeSimdAccel(sc).tree_dump()
     obox, olink, orefs = ora.Accel(ora.Scene(flat), ora.ACCEL_KD_SIMD, W=16).dump()
@@ -62,3 +74,27 @@ def test_frames_match_oracle(rtk, ora, path):
         rgb, cn = acc.render_frame(rtk.RenderConfig(width=160, height=90, spp=3, max_ray_depth=4, diffuse_rays=2, trace_mode=mode))
         assert cn["rays"] == ocn["rays"], mode
         assert np.array_equal(_bits(rgb), _bits(ref)), mode
+
+
+@pytest.mark.gpu
+def test_all_procedural_textures_in_one_scene(rtk, ora, tmp_path):
+    """hw12/scene4 (four textured quads) with its JPEG material re-pointed at the checker texture and a mirror added
+    behind the camera's view, so that albedo / edges / checker are all sampled, directly and through a reflection."""
+    import json
+
+    doc = json.load(open(os.path.join(SCENES, "hw12", "scene4.crtscene")))
+    doc["materials"][3]["albedo"] = "Black White Checker"
+    doc["materials"].append({"type": "reflective", "albedo": [1, 1, 1], "smooth_shading": False})
+    doc["objects"].append({"material_index": 4, "vertices": [-8, -3, -6, 8, -3, -6, 8, -3, 6, -8, -3, 6],
+                           "triangles": [0, 2, 1, 0, 3, 2]})
+    path = tmp_path / "textures.crtscene"
+    path.write_text(json.dumps(doc))
+    acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(str(path)))
+    oacc = ora.Accel(ora.Scene(ora.load_crtscene(str(path))), ora.ACCEL_KD_SIMD)
+    for (w, h, spp, depth, gi) in [(640, 360, 1, 5, 0), (200, 112, 2, 3, 2)]:
+        ref, ocn = oacc.render(w, h, spp, depth, gi)
+        assert len(np.unique(ref.reshape(-1, 3), axis=0)) > 8          # several texture colours are visible
+        for mode in (rtk.TRACE_AUTO, rtk.TRACE_GROUP4, rtk.TRACE_STREAM, rtk.TRACE_LANE):
+            rgb, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=depth, diffuse_rays=gi, trace_mode=mode))
+            assert cn["rays"] == ocn["rays"], mode
+            assert np.array_equal(_bits(rgb), _bits(ref)), mode

@@ -115,7 +115,9 @@ def test_reader_error_reporting(rtk, tmp_path):
     expect(lambda d: d["objects"][0]["triangles"].__setitem__(0, 77), rtk.RTK_ERR_INVALID)    # vertex index out of range
     expect(lambda d: d.pop("lights"), rtk.RTK_ERR_PARSE)
     expect(lambda d: d.pop("camera"), rtk.RTK_ERR_PARSE)
-    expect(lambda d: d["materials"][1].update(albedo="brick"), rtk.RTK_ERR_UNSUPPORTED)       # texture material
+    expect(lambda d: d["materials"][1].update(albedo="brick"), rtk.RTK_ERR_INVALID)           # texture that does not exist
+    expect(lambda d: (d.update(textures=[{"name": "brick", "type": "bitmap", "file_path": "x.jpg"}]),
+                      d["materials"][1].update(albedo="brick")), rtk.RTK_ERR_UNSUPPORTED)     # bitmap texture in use
     ok = rtk.parse_scene_file(_write_scene(tmp_path, lambda d: d["settings"]["image_settings"].update(bucket_size=24)))
     assert ok.info.bucket_size == 24 and ok.info.n_triangles == 2
     assert rtk.parse_scene_file(_write_scene(tmp_path, lambda d: None)).info.bucket_size == 64  # loader.hpp:48
