@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 SCENE = os.path.join(ROOT, "tests", "golden", "scenes", "hw09", "scene5.crtscene")
 WIDTH, HEIGHT, SPP, DEPTH, DIFFUSE = 1920, 1080, 1, 5, 0
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-TRACE_NAMES = {0: "auto", 1: "lane", 2: "wave", 3: "group4", 4: "group8", 5: "group2", 6: "stream", 7: "twopass"}
+TRACE_NAMES = {0: "auto", 1: "lane", 2: "wave", 3: "group4", 4: "group8", 5: "group16", 6: "stream", 7: "twopass"}
 
 
 def measured_traffic(mode_name: str):
@@ -81,6 +81,7 @@ def main() -> None:
     ap.add_argument("--trace-mode", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="N>1: frames in flight (1 = render, gather, assemble back to back)")
     args = ap.parse_args()
 
     import torch
@@ -94,12 +95,15 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RTK_BENCH_FORCE_DIST=1 runs the sharded code path (RCCL group, gather pipeline, assemble) at world size 1 too,
+    # which is how it is rehearsed on a one-GPU box
+    use_dist = world > 1 or (os.environ.get("RTK_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if rank == 0:
         ge.build()                      # a no-op when the in-tree libraries are current (they travel with the snapshot)
-    if world > 1:
+    if use_dist:
         dist.barrier()                  # nobody loads librtk_hip.so while rank 0 might still be writing it
     rtk = importlib.import_module("simd-raytracer_amd")
 
@@ -110,13 +114,42 @@ def main() -> None:
     n_local = accel.output_floats(cfg)
     frame = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
     local = frame.view(-1) if world == 1 else torch.empty((n_local,), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((world, n_local), dtype=torch.float32, device="cuda") if world > 1 else None
+    pipe = None
+    if use_dist:
+        # sharded frames: render(k+1) overlaps all_gather(k) (parallel.FramePipeline); every frame is still rendered,
+        # gathered and assembled on every rank, and the pipeline is drained inside the timed region
+        par = importlib.import_module("simd-raytracer_amd.parallel")
+        layout = par.BucketLayout(WIDTH, HEIGHT, accel.scene.info.bucket_size, world)
+        if world > 1:
+            assert layout.floats_per_rank == n_local, (layout.floats_per_rank, n_local)
+
+            def assemble(g, f):
+                accel.assemble_device(cfg, g.data_ptr(), f.data_ptr(), stream.cuda_stream)
+        else:                                                   # one-GPU rehearsal: a world-1 frame is not bucket-compacted
+
+            def assemble(g, f):
+                f.view(-1).copy_(g)
+        timed = []                                              # HIP event pairs around the render launches
+
+        def render(buf, k):
+            if timed is not None and recording[0]:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                accel.render_frame_device(cfg, buf.data_ptr(), stream.cuda_stream)
+                b.record(stream)
+                timed.append((a, b))
+            else:
+                accel.render_frame_device(cfg, buf.data_ptr(), stream.cuda_stream)
+
+        recording = [False]
+        pipe = par.FramePipeline(layout, accel, cfg, depth=args.pipeline_depth, render=render, assemble=assemble,
+                                 floats_per_rank=n_local)
 
     def step() -> None:
-        accel.render_frame_device(cfg, local.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered.view(-1), local)
-            accel.assemble_device(cfg, gathered.data_ptr(), frame.data_ptr(), stream.cuda_stream)
+        if pipe is None:
+            accel.render_frame_device(cfg, local.data_ptr(), stream.cuda_stream)
+        else:
+            pipe.submit()
 
     # ---- untimed: per-ray work counters of this rank's share (for the algorithmic-byte roofline figure)
     stats_cfg = rtk.RenderConfig(**{**cfg.__dict__, "collect_stats": True})
@@ -125,23 +158,29 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
+    if pipe is not None:
+        pipe.drain()
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps between barrier + synchronize on both sides
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record(stream)           # HIP events on the stream the render kernel is launched on
-        accel.render_frame_device(cfg, local.data_ptr(), stream.cuda_stream)
-        ev[k][1].record(stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered.view(-1), local)
-            accel.assemble_device(cfg, gathered.data_ptr(), frame.data_ptr(), stream.cuda_stream)
+    if pipe is None:
+        for k in range(args.steps):
+            ev[k][0].record(stream)           # HIP events on the stream the render kernel is launched on
+            accel.render_frame_device(cfg, local.data_ptr(), stream.cuda_stream)
+            ev[k][1].record(stream)
+    else:
+        recording[0] = True
+        for k in range(args.steps):
+            pipe.submit()
+        pipe.drain()                          # the last frames are gathered and assembled inside the timed region
+        ev = timed
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
@@ -149,7 +188,7 @@ def main() -> None:
     rays_rank = accel.last_counters()["rays"]
     tot = torch.tensor([float(elapsed), float(rays_rank), float(algorithmic_bytes(work)), float(kernel_ms)],
                        dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone()
@@ -179,7 +218,7 @@ def main() -> None:
             "config": {"workload": "BASELINE configs[1]: scenes/hw09/scene5.crtscene 1920x1080 1spp max_ray_depth=5 "
                                    "(primary + shadow + reflection rays), kd_tree_simd_accel semantics",
                        "rays_per_frame": int(rays_total), "primary_rays": WIDTH * HEIGHT * SPP,
-                       "trace_mode": TRACE_NAMES[args.trace_mode] + (" (= group4 for this fork-free scene)" if args.trace_mode == 0 else ""), "parallelism": f"bucket-tiles x{world}"},
+                       "trace_mode": TRACE_NAMES[args.trace_mode] + (" (= group4 for this fork-free scene)" if args.trace_mode == 0 else ""), "parallelism": f"bucket-tiles x{world}" + (f", RCCL all-gather of frame k overlapped with render k+1 ({args.pipeline_depth} frames in flight)" if pipe is not None else "")},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
@@ -196,7 +235,7 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

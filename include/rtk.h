@@ -50,7 +50,7 @@ enum {
     RTK_TRACE_WAVE = 2,   /* one wave walks the tree once for its 64 rays (scalar node/triangle fetch) */
     RTK_TRACE_GROUP4 = 3, /* frames only: 4 waves share 64 rays and split every large leaf 4 ways (merge through LDS) */
     RTK_TRACE_GROUP8 = 4, /* frames only: same with 8 waves */
-    RTK_TRACE_GROUP2 = 5, /* frames only: same with 2 waves */
+    RTK_TRACE_GROUP16 = 5, /* frames only: same with 16 waves (one 1024-thread workgroup per 8x8 pixel block) */
     RTK_TRACE_STREAM = 6, /* frames only: the ray tree level by level — per-depth path / shadow / combine kernels over
                              compacted ray queues (stream.hip) */
     RTK_TRACE_TWOPASS = 7 /* frames only, spp == 1: camera-ray pass, then the GROUP4 shading pass over the pixel blocks

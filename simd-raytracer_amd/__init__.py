@@ -20,12 +20,12 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "librtk_hip.so")
+_LIB_PATH = os.environ.get("RTK_LIB_OVERRIDE") or os.path.join(_HERE, "librtk_hip.so")     # override: A/B builds (tools/)
 
 RTK_OK, RTK_ERR_INVALID, RTK_ERR_NO_DEVICE, RTK_ERR_HIP, RTK_ERR_IO, RTK_ERR_PARSE, RTK_ERR_UNSUPPORTED = range(7)
 MAT_DIFFUSE, MAT_REFLECTIVE, MAT_REFRACTIVE, MAT_CONSTANT, MAT_TEXTURE = 0, 1, 2, 3, 4
 TEX_ALBEDO, TEX_EDGES, TEX_CHECKER = 0, 1, 2
-TRACE_AUTO, TRACE_LANE, TRACE_WAVE, TRACE_GROUP4, TRACE_GROUP8, TRACE_GROUP2, TRACE_STREAM, TRACE_TWOPASS = 0, 1, 2, 3, 4, 5, 6, 7
+TRACE_AUTO, TRACE_LANE, TRACE_WAVE, TRACE_GROUP4, TRACE_GROUP8, TRACE_GROUP16, TRACE_STREAM, TRACE_TWOPASS = 0, 1, 2, 3, 4, 5, 6, 7
 
 # every symbol include/rtk.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [

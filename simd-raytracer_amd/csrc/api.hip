@@ -70,6 +70,12 @@ struct rtk_accel {
     uint32_t *tp_bins = nullptr;       // [kCostBins] counts, [1] n_listed
     uint32_t *tp_bin_list = nullptr, *tp_order = nullptr;
     size_t tp_pixels = 0, tp_tiles = 0;
+    // cost feedback (megakernel frames): per-pixel-block cost of the last frame of shape fb_sig, and the order made from it
+    uint32_t *fb_cost = nullptr, *fb_order = nullptr;
+    uint8_t *fb_bins = nullptr;
+    size_t fb_units = 0;
+    uint64_t fb_sig[4] = {0, 0, 0, 0};
+    bool fb_valid = false;
     hipStream_t last_stream = nullptr;
     uint64_t last_primary = 0;
     bool last_stats = false;
@@ -110,12 +116,26 @@ int ensure_device(rtk_accel *a) {
     return RTK_OK;
 }
 
+#ifdef RTK_DEBUG_KHIST
+static unsigned long long *g_khist = nullptr;
+extern "C" void rtk_debug_khist(unsigned long long *out64) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out64, g_khist, 64 * 8, hipMemcpyDeviceToHost);
+    (void)hipMemset(g_khist, 0, 64 * 8);
+}
+#endif
 dev::TreeView tree_view(const rtk_accel *a) {
     dev::TreeView t;
     t.nodes = a->d_nodes; t.tris = a->d_tris; t.tri_ids = a->d_tri_ids; t.shade = a->d_shade;
     t.n_nodes = static_cast<uint32_t>(a->tree.dev_nodes.size());
     t.eps = a->params.eps;
     t.normalize = a->params.normalize_hit_normal;
+#ifdef RTK_DEBUG_KHIST
+    static unsigned long long *khist = nullptr;
+    if (!khist) { (void)hipMalloc(reinterpret_cast<void **>(&khist), 64 * 8); (void)hipMemset(khist, 0, 64 * 8); }
+    t.khist = khist;
+    g_khist = khist;
+#endif
     return t;
 }
 
@@ -167,7 +187,7 @@ int ensure_twopass_ws(rtk_accel *a, size_t pixels, size_t tiles) {
 }
 
 bool valid_mode(int m) { return m == RTK_TRACE_AUTO || m == RTK_TRACE_LANE || m == RTK_TRACE_WAVE; }
-bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || m == RTK_TRACE_GROUP8 || m == RTK_TRACE_GROUP2 ||
+bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || m == RTK_TRACE_GROUP8 || m == RTK_TRACE_GROUP16 ||
            m == RTK_TRACE_STREAM || m == RTK_TRACE_TWOPASS; }
 
 struct FrameGeom {
@@ -389,6 +409,7 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
         (void)hipFree(a->ws.node_bins); (void)hipFree(a->ws.hit_bins); (void)hipFree(a->ws.node_order); (void)hipFree(a->ws.hit_order);
         (void)hipFree(a->tp_prim); (void)hipFree(a->tp_bins); (void)hipFree(a->tp_bin_list); (void)hipFree(a->tp_order);
+        (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
     }
     delete a;
 }
@@ -569,6 +590,35 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             std::fprintf(stderr, "\n");
         }
     } else {
+        // Cost feedback: the frame time is set by the few pixel blocks whose rays graze the mesh (hundreds of microseconds
+        // each, against ~3 for a background block).  Started late they are the tail of the frame, so every block reports
+        // its cycle count and the next frame of the same shape starts them most-expensive-first.  Only the launch order
+        // changes: every block is rendered in full, every frame.  RTK_COST_FEEDBACK=0 turns it off.
+        static const bool feedback = [] { const char *e = std::getenv("RTK_COST_FEEDBACK"); return !(e && e[0] == '0'); }();
+        const size_t units = size_t(g.buckets_per_rank) * g.blocks_side * g.blocks_side;
+        A.n_units = uint32_t(units);
+        if (feedback && units > 0 && units <= 0x7FFFFFFFull) {
+            const uint64_t sig[4] = {(uint64_t(uint32_t(g.width)) << 32) | uint32_t(g.height),
+                                     (uint64_t(uint32_t(g.rank)) << 32) | uint32_t(g.world),
+                                     (uint64_t(uint32_t(p->spp)) << 32) | (uint64_t(uint32_t(p->max_ray_depth)) << 16) | uint32_t(p->diffuse_rays),
+                                     (uint64_t(uint32_t(g.bucket)) << 32) | uint32_t(p->trace_mode)};
+            if (a->fb_units != units) {
+                (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
+                a->fb_cost = a->fb_order = nullptr; a->fb_bins = nullptr; a->fb_units = 0; a->fb_valid = false;
+                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_cost), units * sizeof(uint32_t)));
+                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_order), units * sizeof(uint32_t)));
+                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_bins), units));
+                a->fb_units = units;
+            }
+            if (a->fb_valid && std::memcmp(sig, a->fb_sig, sizeof(sig)) == 0) {
+                const hipError_t eo = launch_order_by_cost(a->fb_cost, a->fb_bins, a->fb_order, uint32_t(units), s);
+                if (eo != hipSuccess) return hip_fail(eo, "launch k_order_by_cost");
+                A.order_in = a->fb_order;
+            }
+            A.cost_out = a->fb_cost;
+            std::memcpy(a->fb_sig, sig, sizeof(sig));
+            a->fb_valid = true;
+        }
         // RTK_TRACE_AUTO for frames: workgroup-cooperative leaves (fastest megakernel variant on every config scene)
         const hipError_t e = launch_render(A, p->trace_mode == RTK_TRACE_AUTO ? RTK_TRACE_GROUP4 : p->trace_mode,
                                            p->collect_stats != 0, forks, s);

@@ -93,7 +93,7 @@ struct Frame {            // 15 dwords, lives in scratch; touched only at refrac
 template <int MODE, bool STATS, bool FORKS, bool LDS_NODES, int SLICES, bool PRIMED = false>
 // GROUP4 without per-ray statistics is built for RTK_G4_WAVES (5) waves per SIMD: 96 VGPRs and a 48-byte spill buy a
 // fifth resident workgroup per CU (measured 0.912 -> 0.881 ms on config 2; 6 waves / 80 VGPRs gives no more)
-__global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (SLICES == 4 && !STATS ? RTK_G4_WAVES : 4)) void k_render(RenderArgs A) {
+__global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : SLICES == 8 ? 2 : (SLICES == 4 && !STATS ? RTK_G4_WAVES : 4)) void k_render(RenderArgs A) {
     // PRIMED (second pass of a two-pass frame): pixel blocks come from tile_order (most expensive first) and the
     // camera ray's hit is read from A.prim instead of being traced again
     if (PRIMED && blockIdx.x >= *A.n_listed) return;
@@ -103,20 +103,25 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (
     // the per-lane path reads nodes from LDS; the wave-cooperative paths fetch them with scalar loads instead
     constexpr bool kStage = LDS_NODES && (MODE == RTK_TRACE_LANE || MODE == RTK_TRACE_AUTO);
     if (kStage) stage_nodes(A.tree.nodes, A.tree.n_nodes, lds_nodes);
-    __shared__ GroupShared group_sh[1];
+    __shared__ GroupStorage<(SLICES > 1 ? SLICES : 1)> group_st;
+    GroupShared *const group_sh = group_st.get();
     // the wave index is wave-uniform: say so (readfirstlane) or everything derived from it is compiled per-lane
-    const uint32_t slice = SLICES > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+    // The owner role rotates with the workgroup index: the dispatcher places wave i of every workgroup on SIMD i, so a
+    // fixed owner wave would put every owner of a CU on the same SIMD and leave the other three to the (mostly idle) helpers.
+    const uint32_t slice = SLICES > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((threadIdx.x >> 6) + blockIdx.x) % (uint32_t)SLICES)) : 0u;
     if (SLICES > 1 && slice != 0u) {                 // helper waves (trace.hip.hpp, "Workgroup-cooperative leaves")
-        group_helper_loop<SLICES>(A.tree, &group_sh[0], slice);
+        group_helper_loop<SLICES>(A.tree, group_sh, slice);
         return;
     }
-    SliceCtx sx = {SLICES > 1 ? &group_sh[0] : nullptr, A.slice_min_tris, 0u, true, 0u};
+    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u};
 
     // ---- pixel assignment (tile/bucket.hpp:7-21 buckets, 8x8 blocks inside, round-robin over ranks).
     // SLICES > 1: the whole workgroup serves ONE 8x8 block (wave 0 owns the rays, the others help with big leaves).
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t unit = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t gwave = PRIMED ? A.tile_order[blockIdx.x]
-                                  : (SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+                                  : ((A.order_in != nullptr && unit < A.n_units) ? A.order_in[unit] : unit);
+    const unsigned long long cost_t0 = __builtin_readcyclecounter();
     constexpr bool writer = true;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
     const uint32_t local_bucket = gwave / bpb, sub = gwave % bpb;
@@ -128,6 +133,9 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (
     const uint32_t px = bx + lx, py = by + ly;
     valid = valid & (lx < A.bucket) & (ly < A.bucket) & (px < A.width) & (py < A.height);
 
+#ifdef RTK_DEBUG_PHASES
+    const unsigned long long ph_begin = __builtin_readcyclecounter();
+#endif
 #ifdef RTK_DEBUG_WAVE_TIME
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     uint32_t dbg_iters = 0;
@@ -352,7 +360,13 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (
             }
             primed = false;
         } else {
+#ifdef RTK_DEBUG_PHASES
+            const unsigned long long tr0 = __builtin_readcyclecounter();
+#endif
             cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx);
+#ifdef RTK_DEBUG_PHASES
+            sx.c_trace += __builtin_readcyclecounter() - tr0; sx.n_trace += 1u;
+#endif
         }
 #ifdef RTK_DEBUG_WAVE_TIME
         dbg_iters += 1;
@@ -402,7 +416,21 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (
         o[0] = (float)(dbg_t0 & 0xFFFFFFull); o[1] = (float)(dbg_t1 & 0xFFFFFFull); o[2] = (float)dbg_iters;
     }
 #endif
-    if (SLICES > 1) group_post_exit(&group_sh[0]);
+#ifdef RTK_DEBUG_PHASES
+    if (valid && writer) {
+        const float vals[11] = {(float)(__builtin_readcyclecounter() - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
+                                (float)sx.n_small, (float)sx.t_small, (float)sx.c_small, (float)sx.n_big, (float)sx.t_big, (float)sx.c_big, 0.f};
+        float v = 0.f;
+        for (int i = 0; i < 10; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
+        float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
+        o[0] = v; o[1] = 0.f; o[2] = 0.f;
+    }
+#endif
+    if (A.cost_out != nullptr && lane == 0u && gwave < A.n_units) {        // what this block cost, for the next frame's order
+        const unsigned long long dt = (__builtin_readcyclecounter() - cost_t0) >> 4;
+        A.cost_out[gwave] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
+    }
+    if (SLICES > 1) group_post_exit(group_sh);
     const uint32_t total = wave_sum(nrays);
     if (STATS && writer) flush_stats(st, 0u, A.counters);
     // one no-return atomic per pixel block, spread over 64 words (a single word saturates near 88 atomics/us)
@@ -417,10 +445,11 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 8 ? 2 : (
 // that happened to be dispatched last).
 template <bool STATS, int SLICES>
 __global__ __launch_bounds__(64 * SLICES, 8) void k_primary(RenderArgs A) {
-    __shared__ GroupShared group_sh[1];
-    const uint32_t slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (slice != 0u) { group_helper_loop<SLICES>(A.tree, &group_sh[0], slice); return; }
-    SliceCtx sx = {&group_sh[0], A.slice_min_tris, 0u, true, 0u};
+    __shared__ GroupStorage<(SLICES > 1 ? SLICES : 1)> group_st;
+    GroupShared *const group_sh = group_st.get();
+    const uint32_t slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((threadIdx.x >> 6) + blockIdx.x) % (uint32_t)SLICES));
+    if (slice != 0u) { group_helper_loop<SLICES>(A.tree, group_sh, slice); return; }
+    SliceCtx sx = {group_sh, A.slice_min_tris, 0u, true, 0u};
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gwave = blockIdx.x;
@@ -435,7 +464,7 @@ __global__ __launch_bounds__(64 * SLICES, 8) void k_primary(RenderArgs A) {
     const Ray ray = camera_ray(A, px, py, root_key(pcg_hash(A.seed), py * A.width + px, 0u));
     Stats st = {0, 0, 0, 0, 0, 0};
     const Cand c = trace<RTK_TRACE_WAVE, STATS, false, SLICES>(A.tree, nullptr, ray, true, valid, st, sx);
-    group_post_exit(&group_sh[0]);
+    group_post_exit(group_sh);
 
     const size_t pix = A.out_index(local_bucket, lx, ly, px, py);
     const bool hit = valid & (c.k != kMiss);
@@ -558,9 +587,45 @@ hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool fo
         case RTK_TRACE_WAVE: return launch_render_mode<RTK_TRACE_WAVE, 1>(A, packed, stats, forks, lds, lds_bytes, s);
         case RTK_TRACE_GROUP4: return launch_render_mode<RTK_TRACE_WAVE, 4>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
         case RTK_TRACE_GROUP8: return launch_render_mode<RTK_TRACE_WAVE, 8>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
-        case RTK_TRACE_GROUP2: return launch_render_mode<RTK_TRACE_WAVE, 2>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
+        case RTK_TRACE_GROUP16: return launch_render_mode<RTK_TRACE_WAVE, 16>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
         default: return launch_render_mode<RTK_TRACE_AUTO, 1>(A, packed, stats, forks, lds, lds_bytes, s);
     }
+}
+
+// Counting sort of the pixel blocks by last frame's cost, most expensive first.  One workgroup: a frame has tens of
+// thousands of blocks, the whole job is two passes over a few hundred KB.
+namespace dev {
+__device__ __forceinline__ uint32_t cost_bin(uint32_t c) {                 // 8 bins per octave
+    c |= 1u;
+    const uint32_t e = 31u - (uint32_t)__clz((int)c);
+    const uint32_t m = e >= 3u ? (c >> (e - 3u)) & 7u : (c << (3u - e)) & 7u;
+    return e * 8u + m;                                                     // 0..255
+}
+__global__ __launch_bounds__(1024) void k_order_by_cost(const uint32_t *cost, uint8_t *bins, uint32_t *order, uint32_t n) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t start[256];
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
+    // the bin of every block is computed once and kept: `order` is a permutation even if cost[] changes under us
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t b = cost_bin(cost[i]);
+        bins[i] = (uint8_t)b;
+        atomicAdd(&hist[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t acc = 0u;
+        for (int b = 255; b >= 0; --b) { start[b] = acc; acc += hist[b]; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&start[bins[i]], 1u)] = i;
+}
+}  // namespace dev
+
+hipError_t launch_order_by_cost(const uint32_t *cost, uint8_t *bins, uint32_t *order, uint32_t n, hipStream_t s) {
+    if (n == 0u) return hipSuccess;
+    hipLaunchKernelGGL(dev::k_order_by_cost, dim3(1), dim3(1024), 0, s, cost, bins, order, n);
+    return hipGetLastError();
 }
 
 // Two-pass frame (spp == 1): k_primary -> k_tile_order -> primed k_render, all on one stream.

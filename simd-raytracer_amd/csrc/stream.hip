@@ -164,10 +164,13 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
         __syncthreads();
     }
     // SLICES > 1: the workgroup's wave 0 owns the rays, waves 1.. help with large leaves (trace.hip.hpp)
-    __shared__ GroupShared group_sh[1];
-    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ GroupStorage<(SLICES > 1 ? SLICES : 1)> group_st;
+    GroupShared *const group_sh = group_st.get();
+    // SLICES > 1: role 0 = owner; the owner role rotates with the workgroup index so that owners spread over the SIMDs
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(SLICES > 1 ? ((threadIdx.x >> 6) + blockIdx.x) % (uint32_t)SLICES : (threadIdx.x >> 6)));
     if (SLICES > 1 && wave_in_block != 0u) {
-        group_helper_loop<SLICES>(A.tree, &group_sh[0], wave_in_block);
+        group_helper_loop<SLICES>(A.tree, group_sh, wave_in_block);
         return;
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     const uint32_t level = S.level;
     uint32_t *ctrl = S.ws.ctrl;
     if (ctrl[kCtrlOverflow] != 0u) {                                           // a queue overflowed: the megakernel redoes the frame
-        if (SLICES > 1) group_post_exit(&group_sh[0]);
+        if (SLICES > 1) group_post_exit(group_sh);
         return;
     }
     uint32_t base, count;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     for (uint32_t j = 0; j < level; ++j) hit_base += ctrl[kCtrlHitCount + j];
     const uint32_t n_items = (count + 63u) >> 6;
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {SLICES > 1 ? &group_sh[0] : nullptr, A.slice_min_tris, 0u, true, 0u};
+    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u};
     uint32_t nrays = 0;
 
     for (uint32_t item = gunit; item < n_items; item = LEVEL0 ? n_items : next_item(ctrl + kCtrlTicket + level, n_units_grid)) {
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
             q[1] = make_float4(__uint_as_float(first_child), __uint_as_float(aux), __uint_as_float(nchild), __uint_as_float(pix));
         }
     }
-    if (SLICES > 1) group_post_exit(&group_sh[0]);
+    if (SLICES > 1) group_post_exit(group_sh);
     add_rays(S, st, nrays, STATS, gunit);
 }
 
@@ -339,10 +342,13 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         for (uint32_t i = threadIdx.x; i < A.tree.n_nodes * 2u; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
-    __shared__ GroupShared group_sh[1];
-    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ GroupStorage<(SLICES > 1 ? SLICES : 1)> group_st;
+    GroupShared *const group_sh = group_st.get();
+    // SLICES > 1: role 0 = owner; the owner role rotates with the workgroup index so that owners spread over the SIMDs
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(SLICES > 1 ? ((threadIdx.x >> 6) + blockIdx.x) % (uint32_t)SLICES : (threadIdx.x >> 6)));
     if (SLICES > 1 && wave_in_block != 0u) {
-        group_helper_loop<SLICES>(A.tree, &group_sh[0], wave_in_block);
+        group_helper_loop<SLICES>(A.tree, group_sh, wave_in_block);
         return;
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     const uint32_t n_units_grid = SLICES > 1 ? gridDim.x : gridDim.x * (blockDim.x >> 6);
     uint32_t *ctrl = S.ws.ctrl;
     if (ctrl[kCtrlOverflow] != 0u) {
-        if (SLICES > 1) group_post_exit(&group_sh[0]);
+        if (SLICES > 1) group_post_exit(group_sh);
         return;
     }
     uint32_t hit_base = 0u, n_hits = 0u;
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     const uint32_t n_items = ((n_hits + 63u) >> 6) * n_lights;
     const float PI_F = 3.14159265358979323846f;
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {SLICES > 1 ? &group_sh[0] : nullptr, A.slice_min_tris, 0u, true, 0u};
+    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u};
     uint32_t nrays = 0;
 
     for (uint32_t item = gunit; item < n_items; item = next_item(ctrl + kCtrlTicket + kLevels + S.level, n_units_grid)) {
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         }
         if (valid) S.ws.contrib[(size_t)h * n_lights + k] = make_float2(contrib, clear ? 1.0f : 0.0f);
     }
-    if (SLICES > 1) group_post_exit(&group_sh[0]);
+    if (SLICES > 1) group_post_exit(group_sh);
     add_rays(S, st, nrays, STATS, gunit);
 }
 

@@ -58,6 +58,9 @@ struct TreeView {
     uint32_t n_nodes;
     float eps;
     int normalize;
+#ifdef RTK_DEBUG_KHIST
+    unsigned long long *khist;   // diagnostic: leaf visits by number of participating rays (see tools/khist.py)
+#endif
 };
 
 // Wave-uniform loads: address space 4 (constant) forces s_load_* through the scalar cache, so one
@@ -172,6 +175,20 @@ struct TriS {      // one leaf reference held in SGPRs (wave-uniform)
 // One 32-byte scalar load (v0, e1, e2x, e2y) + one dword (e2z).  As ONE load the first eight floats cannot be split by
 // the compiler into "needed now" and "needed later" halves: split, the later half was sunk to the end of the loop
 // body, right in front of the wait, which exposed a full scalar-cache round trip in every iteration.
+struct NodeS {     // one node held in SGPRs
+    float lo0, lo1, lo2, hi0, hi1, hi2;
+    uint32_t a, b;
+};
+typedef uint32_t uint8x_t __attribute__((ext_vector_type(8)));
+typedef const uint8x_t __attribute__((address_space(4))) *cptr_u32x8;
+__device__ __forceinline__ NodeS load_node_uniform(cptr_u32 np) {
+    const uint8x_t q = *(cptr_u32x8)(const void __attribute__((address_space(4))) *)np;
+    NodeS n;
+    n.lo0 = __uint_as_float(q[0]); n.lo1 = __uint_as_float(q[1]); n.lo2 = __uint_as_float(q[2]);
+    n.hi0 = __uint_as_float(q[3]); n.hi1 = __uint_as_float(q[4]); n.hi2 = __uint_as_float(q[5]);
+    n.a = q[6]; n.b = q[7];
+    return n;
+}
 typedef float float8_t __attribute__((ext_vector_type(8)));
 typedef const float8_t __attribute__((address_space(4))) *cptr_f32x8;
 __device__ __forceinline__ TriS load_tri_uniform(cptr_f32 tp) {
@@ -228,6 +245,92 @@ __device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t fi
     }
 }
 
+// ---- Vector-broadcast variant (experimental, -DRTK_VEC_TREE; measured slower than the scalar-load variant) -------------
+// Scalar loads complete out of order, so a wave can only wait for ALL of them (lgkmcnt(0)): the prefetch can never be
+// more than one triangle deep, and the 225 KB of leaf references stream through a 16 KB scalar cache, so most fetches
+// pay an L2 round trip (measured in situ: ~550 cycles per triangle step, 950 per node step, against ~150 cycles of
+// arithmetic).  Vector loads with the same address in every lane (one request, broadcast by the TA) return IN order:
+// vmcnt lets triangle k be consumed while k+1 and k+2 are in flight.  The loop is unrolled by three so that the three
+// register sets rotate without moves.  `vz` is a per-lane zero the compiler cannot see through; without it the loads
+// would be turned back into scalar loads.
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ uint32_t opaque_lane_zero() {
+    uint32_t z;
+    asm("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+__device__ __forceinline__ TriS load_tri_bcast(const float *tp, const uint32_t vz) {
+    const char *q = reinterpret_cast<const char *>(tp) + vz;
+    const f32x4_a4 a = *reinterpret_cast<const f32x4_a4 *>(q);
+    const f32x4_a4 b = *reinterpret_cast<const f32x4_a4 *>(q + 16);
+    TriS t;
+    t.v0x = a.x; t.v0y = a.y; t.v0z = a.z; t.e1x = a.w;
+    t.e1y = b.x; t.e1z = b.y; t.e2x = b.z; t.e2y = b.w;
+    t.e2z = *reinterpret_cast<const float *>(q + 32);
+    return t;
+}
+
+// One triangle against the wave's rays: the arithmetic of test_triangle with wave-level early outs between the stages
+// (the per-lane predicate is a 64-bit mask in SGPRs, see leaf_range_wave).
+__device__ __forceinline__ void tri_step_wave(const TriS &cur, const uint32_t k, const Ray &r, const bool cull, const float eps,
+                                              const unsigned long long pass_mask, const uint32_t lane, Cand &best) {
+    const float pvx = r.d.y * cur.e2z - r.d.z * cur.e2y;
+    const float pvy = r.d.z * cur.e2x - r.d.x * cur.e2z;
+    const float pvz = r.d.x * cur.e2y - r.d.y * cur.e2x;
+    const float det = cur.e1x * pvx + cur.e1y * pvy + cur.e1z * pvz;
+    unsigned long long m = pass_mask & __builtin_amdgcn_ballot_w64(eps <= (cull ? det : __builtin_fabsf(det)));
+    if (m == 0ull) return;
+    const float inv_det = (1.0f / det);
+    const float tvx = r.o.x - cur.v0x, tvy = r.o.y - cur.v0y, tvz = r.o.z - cur.v0z;
+    const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv_det;
+    m &= __builtin_amdgcn_ballot_w64(0.0f <= u) & __builtin_amdgcn_ballot_w64(u <= 1.0f);
+    if (m == 0ull) return;
+    const float qx = tvy * cur.e1z - tvz * cur.e1y;
+    const float qy = tvz * cur.e1x - tvx * cur.e1z;
+    const float qz = tvx * cur.e1y - tvy * cur.e1x;
+    const float v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv_det;
+    m &= __builtin_amdgcn_ballot_w64(0.0f <= v) & __builtin_amdgcn_ballot_w64(u + v <= 1.0f);
+    if (m == 0ull) return;
+    const float t = (cur.e2x * qx + cur.e2y * qy + cur.e2z * qz) * inv_det;
+    m &= __builtin_amdgcn_ballot_w64(eps < t) & __builtin_amdgcn_ballot_w64(t < best.t);
+    if (m == 0ull) return;
+    if ((m >> lane) & 1ull) { best.t = t; best.u = u; best.v = v; best.k = k; }
+}
+
+__device__ __forceinline__ void leaf_range_bcast(const float *tris, const uint32_t vz, const uint32_t first, const uint32_t lo,
+                                                 const uint32_t hi, const Ray &r, const bool cull, const float eps,
+                                                 const bool pass, Cand &best) {
+    if (lo >= hi) return;
+    const unsigned long long pass_mask = __builtin_amdgcn_ballot_w64(pass);
+    const uint32_t lane = __lane_id();
+    const float *base = tris + (size_t)first * 9;
+    const uint32_t last = hi - 1u;                                         // prefetches past the range re-read its last triangle
+    uint32_t k = lo;
+    TriS A = load_tri_bcast(base + (size_t)k * 9, vz);
+    TriS B = load_tri_bcast(base + (size_t)(k + 1u < hi ? k + 1u : last) * 9, vz);
+    TriS C = load_tri_bcast(base + (size_t)(k + 2u < hi ? k + 2u : last) * 9, vz);
+    for (;;) {
+        tri_step_wave(A, first + k, r, cull, eps, pass_mask, lane, best);
+        if (k + 1u >= hi) break;
+        A = load_tri_bcast(base + (size_t)(k + 3u < hi ? k + 3u : last) * 9, vz);
+        tri_step_wave(B, first + k + 1u, r, cull, eps, pass_mask, lane, best);
+        if (k + 2u >= hi) break;
+        B = load_tri_bcast(base + (size_t)(k + 4u < hi ? k + 4u : last) * 9, vz);
+        tri_step_wave(C, first + k + 2u, r, cull, eps, pass_mask, lane, best);
+        if (k + 3u >= hi) break;
+        C = load_tri_bcast(base + (size_t)(k + 5u < hi ? k + 5u : last) * 9, vz);
+        k += 3u;
+    }
+}
+
+#ifndef RTK_VEC_TREE
+#define RTK_LEAF_RANGE(T_, tris_, first_, lo_, hi_, r_, cull_, pass_, best_) \
+    leaf_range_wave((cptr_f32)(const void *)(T_).tris, first_, lo_, hi_, r_, cull_, (T_).eps, pass_, best_)
+#else
+#define RTK_LEAF_RANGE(T_, tris_, first_, lo_, hi_, r_, cull_, pass_, best_) \
+    leaf_range_bcast(reinterpret_cast<const float *>((T_).tris), vz, first_, lo_, hi_, r_, cull_, (T_).eps, pass_, best_)
+#endif
+
 // Workgroup-cooperative leaves (SLICES > 1).  A workgroup of SLICES waves serves ONE 8x8 pixel block: wave 0 (the
 // owner) holds the 64 rays, runs the shading state machine and walks the tree; waves 1..SLICES-1 are helpers that
 // sleep at a workgroup barrier until the owner reaches a leaf with at least `min_tris` triangles.  The owner then
@@ -239,11 +342,17 @@ struct GroupShared {
     float4 ray_o[64];            // origin xyz (w unused); rewritten only when the owner starts a new ray
     float4 ray_d[64];            // direction xyz
     float best_t[64];            // per-lane best t before the leaf
-    float4 result[8][64];        // winners of slices 1..SLICES-1: t,u,v,k
     unsigned long long pass_mask, cull_mask;
     uint32_t first, count;       // leaf references [first, first+count)
     uint32_t kind;               // 0 = leaf, 1 = exit
     uint32_t ray_gen;            // bumped whenever ray_o/ray_d change
+    uint32_t pad[2];
+    float4 result[][64];         // [SLICES][64] winners of slices 1..SLICES-1: t,u,v,k (storage: GroupStorage<SLICES>)
+};
+template <int SLICES>
+struct alignas(16) GroupStorage {
+    unsigned char raw[sizeof(GroupShared) + (size_t)SLICES * 64 * sizeof(float4)];
+    __device__ __forceinline__ GroupShared *get() { return reinterpret_cast<GroupShared *>(raw); }
 };
 enum : uint32_t { GROUP_LEAF = 0, GROUP_EXIT = 1 };
 
@@ -253,12 +362,18 @@ struct SliceCtx {
     uint32_t ray_gen;    // owner: generation of the rays currently in LDS
     bool rays_dirty;     // owner: the current ray is not in LDS yet
     uint32_t work;       // wave-uniform tally of nodes stepped + triangles iterated (a cost estimate for scheduling)
+#ifdef RTK_DEBUG_PHASES
+    // diagnostic (tools/phase_times.py): cycles and counts of the owner's walk by phase
+    unsigned long long c_small = 0, c_big = 0, c_trace = 0;
+    uint32_t n_steps = 0, n_small = 0, n_big = 0, t_small = 0, t_big = 0, n_trace = 0;
+#endif
 };
 
 // helper waves: serve leaf slices until the owner posts GROUP_EXIT
 template <int SLICES>
 __device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared *sh, const uint32_t slice) {
-    cptr_f32 tris = (cptr_f32)(const void *)T.tris;
+    const uint32_t vz = opaque_lane_zero();
+    (void)vz;
     const uint32_t lane = __lane_id();
     uint32_t my_gen = 0xFFFFFFFFu;
     Ray r;
@@ -279,7 +394,7 @@ __device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared
         Cand mine;
         mine.t = sh->best_t[lane]; mine.u = 0.f; mine.v = 0.f; mine.k = kMiss;
         const uint32_t lo = (count * slice) / (uint32_t)SLICES, hi = (count * (slice + 1u)) / (uint32_t)SLICES;
-        leaf_range_wave(tris, first, lo, hi, r, ((cm >> lane) & 1ull) != 0ull, T.eps, ((pm >> lane) & 1ull) != 0ull, mine);
+        RTK_LEAF_RANGE(T, tris, first, lo, hi, r, ((cm >> lane) & 1ull) != 0ull, ((pm >> lane) & 1ull) != 0ull, mine);
         sh->result[slice][lane] = make_float4(mine.t, mine.u, mine.v, __uint_as_float(mine.k));
         __syncthreads();                                                   // B2: results are in LDS
     }
@@ -296,13 +411,46 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
     const uint32_t end = T.n_nodes;
     uint32_t next = active ? 0u : end;
     uint32_t n = 0;
+    const uint32_t vz = opaque_lane_zero();
+    (void)vz;
+#ifndef RTK_VEC_TREE
     cptr_u32 nodes = (cptr_u32)(const void *)T.nodes;
-    cptr_f32 tris = (cptr_f32)(const void *)T.tris;
+    NodeS cur = load_node_uniform(nodes);
+    uint32_t have = 0u;                                                    // `cur` holds node `have`
+#else
+    // node n is read with two broadcast vector loads; node n+1 (where the walk goes when somebody descends, and
+    // after every leaf) is requested before node n is used, so only the jumps to a skip target wait for memory
+    const char *nodes_b = reinterpret_cast<const char *>(T.nodes);
+    float4 q0 = *reinterpret_cast<const float4 *>(nodes_b + vz);
+    float4 q1 = *reinterpret_cast<const float4 *>(nodes_b + vz + 16);
+    uint32_t have = 0u;                                                    // q0/q1 hold node `have`
+#endif
     while (n < end) {
-        cptr_u32 np = nodes + (size_t)n * 8;
-        const float lo0 = __uint_as_float(np[0]), lo1 = __uint_as_float(np[1]), lo2 = __uint_as_float(np[2]);
-        const float hi0 = __uint_as_float(np[3]), hi1 = __uint_as_float(np[4]), hi2 = __uint_as_float(np[5]);
-        const uint32_t a = np[6], b = np[7];
+#ifndef RTK_VEC_TREE
+        // ONE 32-byte scalar load per node (split into "a,b now, box later" by the compiler it cost two serial scalar-cache
+        // round trips per step), and the descend-successor n+1 is requested before node n is tested: only a jump to a
+        // skip target waits for memory.
+        if (have != n) cur = load_node_uniform(nodes + (size_t)n * 8);
+        const uint32_t n_ahead = n + 1u < end ? n + 1u : n;
+        const NodeS ahead = load_node_uniform(nodes + (size_t)n_ahead * 8);
+        const float lo0 = cur.lo0, lo1 = cur.lo1, lo2 = cur.lo2, hi0 = cur.hi0, hi1 = cur.hi1, hi2 = cur.hi2;
+        const uint32_t a = cur.a, b = cur.b;
+        cur = ahead; have = n_ahead;
+#else
+        if (have != n) {
+            const char *np = nodes_b + (size_t)n * 32;
+            q0 = *reinterpret_cast<const float4 *>(np + vz);
+            q1 = *reinterpret_cast<const float4 *>(np + vz + 16);
+        }
+        const uint32_t n_ahead = n + 1u < end ? n + 1u : n;
+        const char *np1 = nodes_b + (size_t)n_ahead * 32;
+        const float4 p0 = *reinterpret_cast<const float4 *>(np1 + vz);
+        const float4 p1 = *reinterpret_cast<const float4 *>(np1 + vz + 16);
+        const float lo0 = q0.x, lo1 = q0.y, lo2 = q0.z, hi0 = q0.w, hi1 = q1.x, hi2 = q1.y;
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q1.z));
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q1.w));
+        q0 = p0; q1 = p1; have = n_ahead;
+#endif
         const bool part = (next == n);
         const unsigned long long part_mask = __builtin_amdgcn_ballot_w64(part);
         if (part_mask == 0ull) {                                           // nobody is waiting here
@@ -316,6 +464,9 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
         if (STATS) { st.nodes += part ? 1u : 0u; st.boxpass += pass ? 1u : 0u; }
         const bool any_pass = wave_any(pass);
         sx.work += (any_pass && b != DEV_INNER) ? b + 2u : 2u;
+#ifdef RTK_DEBUG_PHASES
+        sx.n_steps += 1u;
+#endif
         if (b == DEV_INNER) {
             if (part) next = pass ? n + 1 : a;
             n = any_pass ? n + 1 : a;
@@ -323,6 +474,18 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
             if (part) next = n + 1;
             if (any_pass) {
                 if (STATS && pass) { st.leaves += 1; st.tris += b; st.packets16 += (b + 15u) >> 4; }
+#ifdef RTK_DEBUG_KHIST
+                const uint32_t k = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pass));
+                if (STATS && __lane_id() == 0u) {
+                    const uint32_t kb = k <= 2u ? 0u : k <= 4u ? 1u : k <= 8u ? 2u : k <= 16u ? 3u : k <= 32u ? 4u : 5u;
+                    const uint32_t tb = b < 12u ? 0u : b < 64u ? 1u : b < 192u ? 2u : 3u;
+                    atomicAdd(T.khist + tb * 8u + kb, (unsigned long long)b);
+                    atomicAdd(T.khist + 32u + tb * 8u + kb, 1ull);
+                }
+#endif
+#ifdef RTK_DEBUG_PHASES
+                const unsigned long long ph0 = __builtin_readcyclecounter();
+#endif
                 if (SLICES > 1 && b >= sx.min_tris) {
                     GroupShared *sh = sx.sh;
                     const uint32_t lane = __lane_id();
@@ -339,7 +502,7 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
                         sh->first = a; sh->count = b; sh->kind = GROUP_LEAF; sh->ray_gen = sx.ray_gen;
                     }
                     __syncthreads();                                       // B1: helpers start on their slices
-                    leaf_range_wave(tris, a, 0u, b / (uint32_t)SLICES, r, cull, T.eps, pass, best);
+                    RTK_LEAF_RANGE(T, tris, a, 0u, b / (uint32_t)SLICES, r, cull, pass, best);
                     __syncthreads();                                       // B2: helper results are in LDS
 #pragma unroll
                     for (int s = 1; s < SLICES; ++s) {
@@ -347,8 +510,15 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
                         if (c.x < best.t) { best.t = c.x; best.u = c.y; best.v = c.z; best.k = __float_as_uint(c.w); }
                     }
                 } else {
-                    leaf_range_wave(tris, a, 0u, b, r, cull, T.eps, pass, best);
+                    RTK_LEAF_RANGE(T, tris, a, 0u, b, r, cull, pass, best);
                 }
+#ifdef RTK_DEBUG_PHASES
+                {
+                    const unsigned long long ph1 = __builtin_readcyclecounter();
+                    if (SLICES > 1 && b >= sx.min_tris) { sx.c_big += ph1 - ph0; sx.n_big += 1u; sx.t_big += b; }
+                    else { sx.c_small += ph1 - ph0; sx.n_small += 1u; sx.t_small += b; }
+                }
+#endif
             }
             n = n + 1;
         }

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 MODES = {"auto": 0, "lane": 1, "wave": 2}                       # batched intersect
-FRAME_MODES = {**MODES, "group4": 3, "group8": 4, "group2": 5, "stream": 6, "twopass": 7}   # frames: + workgroup-cooperative leaves, streaming pipeline
+FRAME_MODES = {**MODES, "group4": 3, "group8": 4, "group16": 5, "stream": 6, "twopass": 7}   # frames: + workgroup-cooperative leaves, streaming pipeline
 
 
 def _bits(a):
@@ -235,6 +235,37 @@ def test_sharded_frames_assemble_to_the_unsharded_frame(rtk, ora, scene, w, h, w
     acc.assemble_device(cfgs[0], gathered.data_ptr(), out.data_ptr(), stream)
     torch.cuda.synchronize()
     assert np.array_equal(_bits(out.cpu().numpy()), _bits(base))
+
+
+@pytest.mark.parametrize("mode", ["group4", "wave", "lane", "group16"])
+def test_cost_feedback_reorders_blocks_but_not_results(rtk, ora, mode):
+    """From the second frame of a shape on, the megakernel starts its pixel blocks most-expensive-first, using the cycle
+    counts the previous frame reported (api.hip "cost feedback").  Frames 1, 2, 3 must all be the oracle's frame, also when
+    another shape is rendered in between, and for a rank of a sharded frame."""
+    import torch
+
+    acc, oacc = _scene_pair(rtk, ora, SCENE5)
+    ref, ocn = oacc.render(333, 190, 1, 5, 0)
+    cfg = rtk.RenderConfig(width=333, height=190, max_ray_depth=5, trace_mode=FRAME_MODES[mode])
+    other = rtk.RenderConfig(width=100, height=60, max_ray_depth=5, trace_mode=FRAME_MODES[mode])
+    ref_other, _ = oacc.render(100, 60, 1, 5, 0)
+    for i in range(4):
+        rgb, cn = acc.render_frame(cfg)
+        assert cn["rays"] == ocn["rays"], i
+        assert np.array_equal(_bits(rgb), _bits(ref)), i
+        if i == 2:                                                  # a different shape invalidates the recorded costs
+            rgb2, _ = acc.render_frame(other)
+            assert np.array_equal(_bits(rgb2), _bits(ref_other))
+    # one rank of a 3-way sharded frame, three times: the compact bucket buffer must not change
+    scfg = rtk.RenderConfig(width=333, height=190, max_ray_depth=5, trace_mode=FRAME_MODES[mode], rank=1, world_size=3)
+    n = acc.output_floats(scfg)
+    outs = []
+    for i in range(3):
+        buf = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+        acc.render_frame_device(scfg, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(buf.cpu().numpy())
+    assert np.array_equal(_bits(outs[0]), _bits(outs[1])) and np.array_equal(_bits(outs[0]), _bits(outs[2]))
 
 
 def test_streaming_pipeline_queue_overflow_falls_back_to_the_megakernel(rtk, ora, monkeypatch):

@@ -62,3 +62,50 @@ def test_layout_matches_the_c_abi(rtk):
         covered = sorted(b for r in range(world) for b in lay.buckets_of(r))
         assert covered == list(range(lay.n_buckets))
     assert acc.output_floats(rtk.RenderConfig(width=50, height=20)) == 50 * 20 * 3
+
+
+def _pipeline_worker(rank, world, port, frame_np, bucket, depth, n_frames, result_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        par = importlib.import_module("simd-raytracer_amd.parallel")
+        base = torch.from_numpy(frame_np)
+        h, w, _ = base.shape
+        layout = par.BucketLayout(w, h, bucket, world)
+
+        def frame_k(k):                                     # a frame sequence: frame k = base + k
+            return base + float(k)
+
+        def render(local, k):                               # stands in for rtk_render_frame_device of this rank's buckets
+            local.copy_(par.extract_rank_buckets(frame_k(k), layout, rank))
+
+        def assemble(gathered, frame):                      # CPU mirror of k_assemble
+            frame.copy_(par.assemble_host(gathered, layout))
+
+        pipe = par.FramePipeline(layout, depth=depth, device="cpu", render=render, assemble=assemble)
+        done = []
+        for _ in range(n_frames):
+            r = pipe.submit()
+            if r is not None:
+                done.append((r[0], r[1].clone()))
+        in_flight = n_frames - len(done)
+        done += [(k, f.clone()) for k, f in pipe.drain()]
+        ok = [k for k, _ in done] == list(range(n_frames)) and in_flight == min(depth - 1, n_frames)
+        ok = ok and all(torch.equal(f, frame_k(k)) for k, f in done)
+        np.save(os.path.join(result_dir, f"pipe_{rank}.npy"), np.array([ok]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("depth,n_frames", [(1, 3), (2, 5), (3, 2)])
+def test_frame_pipeline_retires_every_frame_in_order(ora, tmp_path, depth, n_frames):
+    """bench.py's N>1 step: gather(k) is asynchronous and overlaps render(k+1); every frame must still come out,
+    in order, bit-identical, on every rank, and `depth-1` frames are in flight until the drain."""
+    flat = ora.load_crtscene(SCENE5)
+    frame, _ = ora.Accel(ora.Scene(flat), ora.ACCEL_KD_SIMD).render(150, 70, 1, 5, 0, n_threads=2)
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(2, port, frame, flat.bucket_size, depth, n_frames, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(tmp_path / f"pipe_{r}.npy")[0] == 1, f"rank {r}"

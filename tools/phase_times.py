@@ -1,0 +1,36 @@
+"""Diagnostic (-DRTK_DEBUG_PHASES build): where an owner wave's cycles go (node walk / small leaves / sliced leaves / shading)."""
+import ctypes as C, importlib, os, sys, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+rtk = importlib.import_module("simd-raytracer_amd")
+dbg = C.CDLL(sys.argv[1])
+dbg.rtk_render_frame.argtypes = rtk.lib().rtk_render_frame.argtypes
+dbg.rtk_scene_load_crtscene.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+dbg.rtk_accel_build.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+sc = C.c_void_p(); assert dbg.rtk_scene_load_crtscene(os.path.join(ROOT, "tests/golden/scenes/hw09/scene5.crtscene").encode(), C.byref(sc)) == 0
+ac = C.c_void_p(); assert dbg.rtk_accel_build(sc, None, C.byref(ac)) == 0
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+w, h = 1920, 1080
+p = rtk.RenderConfig(width=w, height=h, trace_mode=mode).to_c()
+rgb = np.zeros((h, w, 3), np.float32); cn = rtk.Counters()
+for _ in range(2): assert dbg.rtk_render_frame(ac, C.byref(p), rgb.ctypes.data, C.byref(cn)) == 0
+# lane i of block (by, bx) wrote value i at pixel (by*8 + i//8, bx*8 + i%8)
+r = rgb[:, :, 0].reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)[:, :10].astype(np.float64)
+names = ["total", "trace", "n_trace", "steps", "n_small", "t_small", "c_small", "n_big", "t_big", "c_big"]
+def show(tag, m):
+    s = r[m].sum(0); d = dict(zip(names, s)); n = m.sum()
+    c_nodes = d["trace"] - d["c_small"] - d["c_big"]
+    print(f"--- {tag}: {n} blocks, mean total {d['total']/n:.0f} cycles; trace {100*d['trace']/d['total']:.0f}% "
+          f"(nodes {100*c_nodes/d['total']:.0f}%, small leaves {100*d['c_small']/d['total']:.0f}%, sliced leaves {100*d['c_big']/d['total']:.0f}%), rest {100*(1-d['trace']/d['total']):.0f}%")
+    print(f"    per block: traces {d['n_trace']/n:.1f}, node steps {d['steps']/n:.0f} ({c_nodes/max(d['steps'],1):.0f} cyc/step), "
+          f"small leaves {d['n_small']/n:.1f} with {d['t_small']/n:.0f} tris ({d['c_small']/max(d['t_small'],1):.0f} cyc/tri), "
+          f"sliced leaves {d['n_big']/n:.1f} with {d['t_big']/n:.0f} tris ({d['c_big']/max(d['n_big'],1):.0f} cyc/leaf, {d['c_big']/max(d['t_big'],1):.0f} cyc/tri)")
+tot = r[:, 0]
+show("all", tot >= 0)
+show("traced >1", r[:, 2] > 1)
+order = np.argsort(-tot)
+top = np.zeros(len(tot), bool); top[order[:100]] = True
+show("100 longest", top)
+top = np.zeros(len(tot), bool); top[order[:1000]] = True
+show("1000 longest", top)

@@ -1,0 +1,31 @@
+"""What each rank of an N-GPU run would spend in its render kernel, measured on ONE GPU: renders rank r of world N
+(bucket i -> rank i % N) for every r and reports the slowest rank (the one the frame waits for)."""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+rtk = importlib.import_module("simd-raytracer_amd")
+S = os.path.join(ROOT, "tests/golden/scenes")
+acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(f"{S}/hw09/scene5.crtscene"))
+modes = [int(m) for m in os.environ.get("TC_MODES", "0 7").split()]
+st = torch.cuda.current_stream()
+base = {}
+for world in (1, 2, 4, 8):
+    for mode in modes:
+        times, rays = [], []
+        for rank in range(world):
+            cfg = rtk.RenderConfig(width=1920, height=1080, spp=1, max_ray_depth=5, trace_mode=mode, rank=rank, world_size=world)
+            out = torch.empty((acc.output_floats(cfg),), dtype=torch.float32, device="cuda")
+            for _ in range(5): acc.render_frame_device(cfg, out.data_ptr(), st.cuda_stream)
+            torch.cuda.synchronize()
+            n = 40
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            for _ in range(n): acc.render_frame_device(cfg, out.data_ptr(), st.cuda_stream)
+            b.record(st)
+            torch.cuda.synchronize()
+            times.append(a.elapsed_time(b) / n)
+            rays.append(acc.last_counters()["rays"])
+        if world == 1: base[mode] = max(times)
+        print(f"world {world} mode {mode}: slowest rank {max(times):.3f} ms, fastest {min(times):.3f} ms, rays/rank {min(rays)}..{max(rays)}, "
+              f"kernel-only scaling {base[mode] / max(times):.2f}x", flush=True)

@@ -13,13 +13,23 @@ sc = C.c_void_p(); dbg.rtk_scene_load_crtscene(os.path.join(ROOT, "tests/golden/
 ac = C.c_void_p(); dbg.rtk_accel_build(sc, None, C.byref(ac))
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 w, h = 1920, 1080
-p = rtk.RenderConfig(width=w, height=h, trace_mode=mode).to_c()
-rgb = np.zeros((h, w, 3), np.float32); cn = rtk.Counters()
+world, rank = int(os.environ.get("WT_WORLD", "1")), int(os.environ.get("WT_RANK", "0"))
+p = rtk.RenderConfig(width=w, height=h, trace_mode=mode, rank=rank, world_size=world).to_c()
+if world > 1:                      # compact bucket buffer [buckets_per_rank][64][64][3]; blocks outside the frame stay zero
+    nn = C.c_size_t(); dbg.rtk_render_output_floats.argtypes = rtk.lib().rtk_render_output_floats.argtypes
+    assert dbg.rtk_render_output_floats(ac, C.byref(p), C.byref(nn)) == 0
+    n = nn.value
+    rgb = np.zeros((n // (64 * 3), 64, 3), np.float32)
+else:
+    rgb = np.zeros((h, w, 3), np.float32)
+cn = rtk.Counters()
 for _ in range(3):
     rc = dbg.rtk_render_frame(ac, C.byref(p), rgb.ctypes.data, C.byref(cn))
 assert rc == 0
 # one sample per 8x8 block (all lanes of a wave wrote the same values)
 t0 = rgb[::8, ::8, 0].astype(np.float64); t1 = rgb[::8, ::8, 1].astype(np.float64); it = rgb[::8, ::8, 2]
+live = t0 > 0
+t0, t1, it = t0[live].reshape(1, -1), t1[live].reshape(1, -1), it[live].reshape(1, -1)
 t1 = np.where(t1 < t0, t1 + 2**24, t1)
 med = np.median(t0)
 wrap = t0 < med - 2**23
