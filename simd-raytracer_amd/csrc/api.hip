@@ -606,14 +606,19 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
                 (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
                 a->fb_cost = a->fb_order = nullptr; a->fb_bins = nullptr; a->fb_units = 0; a->fb_valid = false;
                 RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_cost), units * sizeof(uint32_t)));
-                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_order), units * sizeof(uint32_t)));
+                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_order), (units + 2) * sizeof(uint32_t)));   // + header
                 RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_bins), units));
                 a->fb_units = units;
             }
             if (a->fb_valid && std::memcmp(sig, a->fb_sig, sizeof(sig)) == 0) {
-                const hipError_t eo = launch_order_by_cost(a->fb_cost, a->fb_bins, a->fb_order, uint32_t(units), s);
+                // blocks that cost less than this many cycles (background, a handful of nodes) are packed four to a workgroup
+                static const uint32_t light_cycles = [] { const char *e = std::getenv("RTK_LIGHT_BELOW_CYCLES"); return e ? uint32_t(std::atol(e)) : 40000u; }();
+                const bool group_mode = p->trace_mode == RTK_TRACE_AUTO || p->trace_mode == RTK_TRACE_GROUP4 ||
+                                        p->trace_mode == RTK_TRACE_GROUP8 || p->trace_mode == RTK_TRACE_GROUP16;
+                const hipError_t eo = launch_order_by_cost(a->fb_cost, a->fb_bins, a->fb_order, a->fb_order + units, uint32_t(units),
+                                                           group_mode ? light_cycles >> 4 : 0u, s);
                 if (eo != hipSuccess) return hip_fail(eo, "launch k_order_by_cost");
-                A.order_in = a->fb_order;
+                A.order_in = a->fb_order; A.order_hdr = a->fb_order + units;
             }
             A.cost_out = a->fb_cost;
             std::memcpy(a->fb_sig, sig, sizeof(sig));

@@ -106,21 +106,41 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     __shared__ GroupStorage<(SLICES > 1 ? SLICES : 1)> group_st;
     GroupShared *const group_sh = group_st.get();
     // the wave index is wave-uniform: say so (readfirstlane) or everything derived from it is compiled per-lane
+    const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // The owner role rotates with the workgroup index: the dispatcher places wave i of every workgroup on SIMD i, so a
     // fixed owner wave would put every owner of a CU on the same SIMD and leave the other three to the (mostly idle) helpers.
-    const uint32_t slice = SLICES > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((threadIdx.x >> 6) + blockIdx.x) % (uint32_t)SLICES)) : 0u;
+    uint32_t slice = SLICES > 1 ? (wave_in_wg + blockIdx.x) % (uint32_t)SLICES : 0u;
+    // ---- which 8x8 pixel block (tile/bucket.hpp:7-21 buckets, 8x8 blocks inside, round-robin over ranks).
+    // SLICES > 1: the whole workgroup serves ONE block (one wave owns the rays, the others help with big leaves) -- except
+    // for the blocks the cost feedback found cheap (background, a few nodes): those are packed SLICES to a workgroup,
+    // every wave renders its own and nobody helps ("light" workgroups; they never touch the barrier protocol).
+    // (Cutting the most expensive blocks into 4x4-pixel quadrants was tried and dropped: a quadrant's rays visit the same
+    // leaves as the whole block's, so it cost as much as the block.)
+    uint32_t gwave;
+    bool light = false;
+    if (PRIMED) {
+        gwave = A.tile_order[blockIdx.x];
+    } else if (SLICES > 1 && A.order_in != nullptr) {
+        const uint32_t n_single = A.order_hdr[0], n_total = A.order_hdr[1];
+        if (blockIdx.x < n_single) {
+            gwave = A.order_in[blockIdx.x];
+        } else {
+            const uint32_t idx = n_single + (blockIdx.x - n_single) * (uint32_t)SLICES + wave_in_wg;
+            if (idx >= n_total) return;
+            gwave = A.order_in[idx];
+            light = true;
+            slice = 0u;
+        }
+    } else {
+        const uint32_t unit = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+        gwave = (A.order_in != nullptr && unit < A.n_units) ? A.order_in[unit] : unit;
+    }
     if (SLICES > 1 && slice != 0u) {                 // helper waves (trace.hip.hpp, "Workgroup-cooperative leaves")
         group_helper_loop<SLICES>(A.tree, group_sh, slice);
         return;
     }
-    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u};
-
-    // ---- pixel assignment (tile/bucket.hpp:7-21 buckets, 8x8 blocks inside, round-robin over ranks).
-    // SLICES > 1: the whole workgroup serves ONE 8x8 block (wave 0 owns the rays, the others help with big leaves).
+    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, light ? 0xFFFFFFFFu : A.slice_min_tris, 0u, true, 0u};
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t unit = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t gwave = PRIMED ? A.tile_order[blockIdx.x]
-                                  : ((A.order_in != nullptr && unit < A.n_units) ? A.order_in[unit] : unit);
     const unsigned long long cost_t0 = __builtin_readcyclecounter();
     constexpr bool writer = true;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
@@ -363,7 +383,11 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
 #ifdef RTK_DEBUG_PHASES
             const unsigned long long tr0 = __builtin_readcyclecounter();
 #endif
-            cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx);
+            // shadow rays of scenes without transmissive materials only ask "is the closest hit nearer than the light":
+            // they may stop at the first hit that says yes (trace(), `exit_t`).  The work counters are the reference's,
+            // so the STATS build traces every ray to the end.
+            const float exit_t = (!STATS && !A.has_refractive && pend == PEND_SHADOW) ? shadow_max_t : -1.0f;
+            cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx, kAutoMinLanes, exit_t);
 #ifdef RTK_DEBUG_PHASES
             sx.c_trace += __builtin_readcyclecounter() - tr0; sx.n_trace += 1u;
 #endif
@@ -430,7 +454,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         const unsigned long long dt = (__builtin_readcyclecounter() - cost_t0) >> 4;
         A.cost_out[gwave] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
     }
-    if (SLICES > 1) group_post_exit(group_sh);
+    if (SLICES > 1 && !light) group_post_exit(group_sh);
     const uint32_t total = wave_sum(nrays);
     if (STATS && writer) flush_stats(st, 0u, A.counters);
     // one no-return atomic per pixel block, spread over 64 words (a single word saturates near 88 atomics/us)
@@ -601,7 +625,8 @@ __device__ __forceinline__ uint32_t cost_bin(uint32_t c) {                 // 8 
     const uint32_t m = e >= 3u ? (c >> (e - 3u)) & 7u : (c << (3u - e)) & 7u;
     return e * 8u + m;                                                     // 0..255
 }
-__global__ __launch_bounds__(1024) void k_order_by_cost(const uint32_t *cost, uint8_t *bins, uint32_t *order, uint32_t n) {
+__global__ __launch_bounds__(1024) void k_order_by_cost(const uint32_t *cost, uint8_t *bins, uint32_t *order, uint32_t *hdr, uint32_t n,
+                                                        uint32_t light_below) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t start[256];
     for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) hist[i] = 0u;
@@ -614,17 +639,23 @@ __global__ __launch_bounds__(1024) void k_order_by_cost(const uint32_t *cost, ui
     }
     __syncthreads();
     if (threadIdx.x == 0u) {
-        uint32_t acc = 0u;
-        for (int b = 255; b >= 0; --b) { start[b] = acc; acc += hist[b]; }
+        uint32_t acc = 0u, n_single = n;
+        const int light_bin = light_below > 0u ? (int)cost_bin(light_below) : 0;       // bins below it are "light"
+        for (int b = 255; b >= 0; --b) {
+            if (b == light_bin - 1) n_single = acc;
+            start[b] = acc; acc += hist[b];
+        }
+        hdr[0] = n_single; hdr[1] = n;                                      // order[0, n_single): one workgroup each; the rest packed
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&start[bins[i]], 1u)] = i;
 }
 }  // namespace dev
 
-hipError_t launch_order_by_cost(const uint32_t *cost, uint8_t *bins, uint32_t *order, uint32_t n, hipStream_t s) {
+hipError_t launch_order_by_cost(const uint32_t *cost, uint8_t *bins, uint32_t *order, uint32_t *hdr, uint32_t n,
+                                uint32_t light_below, hipStream_t s) {
     if (n == 0u) return hipSuccess;
-    hipLaunchKernelGGL(dev::k_order_by_cost, dim3(1), dim3(1024), 0, s, cost, bins, order, n);
+    hipLaunchKernelGGL(dev::k_order_by_cost, dim3(1), dim3(1024), 0, s, cost, bins, order, hdr, n, light_below);
     return hipGetLastError();
 }
 

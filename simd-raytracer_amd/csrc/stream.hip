@@ -399,7 +399,9 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         bool pending = valid & (0.0f < radius);                              // is_occluded's loop guard, render.hpp:114
         bool clear = true;
         while (wave_any(pending)) {
-            const Cand c = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, false, pending, st, sx, S.auto_min_lanes);
+            // no transmissive material in the scene: the query may stop at the first hit nearer than the light (trace(), `exit_t`)
+            const float exit_t = (!STATS && !A.has_refractive) ? max_t : -1.0f;
+            const Cand c = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, false, pending, st, sx, S.auto_min_lanes, exit_t);
             if (pending) {
                 nrays += 1u;
                 bool clr = (c.k == kMiss) | (max_t < c.t);                   // :117

@@ -133,7 +133,7 @@ __device__ __forceinline__ void test_triangle(const float v0x, const float v0y, 
 // `n` and `best` are the complete traversal state, which is what lets the wave path hand over mid-tree.
 template <bool STATS, bool LDS_NODES>
 __device__ __forceinline__ void trace_lane_from(const TreeView &T, const DevNode *lds_nodes, const Ray &r, const bool cull,
-                                                uint32_t n, Cand &best, Stats &st) {
+                                                uint32_t n, Cand &best, Stats &st, const float exit_t = -1.0f) {
     const uint32_t end = T.n_nodes;
     for (;;) {
         uint32_t leaf_first = 0, leaf_count = 0;
@@ -157,6 +157,7 @@ __device__ __forceinline__ void trace_lane_from(const TreeView &T, const DevNode
             test_triangle(tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7], tp[8], r, cull, T.eps, leaf_first + k,
                           true, best);
         }
+        if (best.t <= exit_t) break;                                       // occlusion query answered (see trace())
     }
 }
 
@@ -407,7 +408,8 @@ __device__ __forceinline__ void group_post_exit(GroupShared *sh) {
 
 template <bool STATS, int SLICES>
 __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, const bool cull, const bool active,
-                                               Cand &best, Stats &st, const uint32_t min_lanes, SliceCtx &sx) {
+                                               Cand &best, Stats &st, const uint32_t min_lanes, SliceCtx &sx,
+                                               const float exit_t = -1.0f) {
     const uint32_t end = T.n_nodes;
     uint32_t next = active ? 0u : end;
     uint32_t n = 0;
@@ -519,6 +521,9 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
                     else { sx.c_small += ph1 - ph0; sx.n_small += 1u; sx.t_small += b; }
                 }
 #endif
+                // occlusion queries: a lane whose hit already answers the query stops; when nobody is left the walk ends
+                if (best.t <= exit_t) next = end;
+                if (__builtin_amdgcn_ballot_w64(next < end) == 0ull) break;
             }
             n = n + 1;
         }
@@ -530,22 +535,27 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
 // (wave-cooperative while at least `kAutoMinLanes` rays share the node, then per-lane from where each ray stands).
 constexpr uint32_t kAutoMinLanes = 12;
 
+// `exit_t` (per lane, default "never"): the caller only wants to know whether the closest hit has t <= exit_t
+// (is_occluded, render.hpp:110-131, for scenes without transmissive materials).  The lane then stops at the end of
+// the first leaf that gives it such a hit: what it has evaluated up to there is a PREFIX of what the reference
+// evaluates (same order, same pruning), the reference's closest hit can only be nearer, so the answer is the same.
 template <int MODE, bool STATS, bool LDS_NODES, int SLICES = 1>
 __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_nodes, const Ray &r, const bool cull,
-                                      const bool active, Stats &st, SliceCtx &sx, const uint32_t auto_min = kAutoMinLanes) {
+                                      const bool active, Stats &st, SliceCtx &sx, const uint32_t auto_min = kAutoMinLanes,
+                                      const float exit_t = -1.0f) {
     Cand best;
     best.t = kFltMax; best.u = 0.0f; best.v = 0.0f; best.k = kMiss;
     sx.rays_dirty = true;
     if (MODE == RTK_TRACE_LANE) {
-        trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, active ? 0u : T.n_nodes, best, st);
+        trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, active ? 0u : T.n_nodes, best, st, exit_t);
     } else if (MODE == RTK_TRACE_WAVE) {
-        if (wave_any(active)) (void)trace_wave<STATS, SLICES>(T, r, cull, active, best, st, 1u, sx);
+        if (wave_any(active)) (void)trace_wave<STATS, SLICES>(T, r, cull, active, best, st, 1u, sx, exit_t);
     } else {
         const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
         if (am != 0ull) {
             uint32_t next = active ? 0u : T.n_nodes;
-            if ((uint32_t)__popcll(am) >= auto_min) next = trace_wave<STATS, 1>(T, r, cull, active, best, st, auto_min, sx);
-            trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, next, best, st);
+            if ((uint32_t)__popcll(am) >= auto_min) next = trace_wave<STATS, 1>(T, r, cull, active, best, st, auto_min, sx, exit_t);
+            trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, next, best, st, exit_t);
         }
     }
     if (STATS && best.k != kMiss) st.hits += 1;
