@@ -140,7 +140,9 @@ typedef struct {
     float shadow_bias, reflection_bias, refraction_bias;
     int32_t trace_mode;             /* RTK_TRACE_* */
     int32_t rank, world_size;       /* bucket i is rendered by rank i % world_size; world_size <= 1: whole frame */
-    int32_t collect_stats;          /* 1 = also count nodes/leaves/triangles per ray (slower kernel variant) */
+    int32_t collect_stats;          /* 1 = also count nodes/leaves/triangles per ray, as the reference algorithm visits them
+                                     * (slower kernel variant); 2 = count what the production path visits (its occlusion
+                                     * queries stop at the first answering hit when no material is transmissive; same frame) */
 } rtk_render_params;
 
 typedef struct {

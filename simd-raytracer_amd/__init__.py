@@ -277,13 +277,13 @@ class RenderConfig:
     trace_mode: int = TRACE_AUTO
     rank: int = 0
     world_size: int = 1
-    collect_stats: bool = False
+    collect_stats: int = 0     # 1 (or True): per-ray work counters of the reference algorithm; 2: of the production path (early-exit occlusion queries)
 
     def to_c(self) -> RenderParams:
         return RenderParams(self.width, self.height, self.spp, self.max_ray_depth, self.diffuse_rays, self.seed,
                             self.fov_degrees, np.float32(self.shadow_bias), np.float32(self.reflection_bias),
                             np.float32(self.refraction_bias), self.trace_mode, self.rank, self.world_size,
-                            1 if self.collect_stats else 0)
+                            int(self.collect_stats))
 
 
 class KdTreeSimdAccel:

@@ -75,7 +75,9 @@ struct rtk_accel {
     uint8_t *fb_bins = nullptr;
     size_t fb_units = 0;
     uint64_t fb_sig[4] = {0, 0, 0, 0};
-    bool fb_valid = false;
+    bool fb_valid = false;           // fb_cost holds the costs of a frame of shape fb_sig
+    bool fb_order_valid = false;     // fb_order was made from such costs
+    unsigned fb_age = 0;             // frames rendered with the current order
     hipStream_t last_stream = nullptr;
     uint64_t last_primary = 0;
     bool last_stats = false;
@@ -516,6 +518,14 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     A.slice_min_tris = kSliceMinTrisDefault;
     if (const char *e = std::getenv("RTK_SLICE_MIN_TRIS")) { const int v = std::atoi(e); if (v > 0) A.slice_min_tris = uint32_t(v); }
     const bool forks = a->has_refractive || p->diffuse_rays > 0;
+    // the megakernel comes in two builds: the lean one (diffuse / reflective / constant materials only) and the general one
+    // (template FORKS: + refraction, diffuse GI, textures), so that the lean one does not carry the general one's registers
+    const bool general = forks || !a->scene.textures.empty();
+    // Occlusion queries (is_occluded) may stop at the first hit nearer than the light when no material is transmissive: the
+    // frame is bit-identical (trace.hip.hpp, `exit_t`), only the per-ray work counters shrink.  collect_stats == 1 counts the
+    // reference's work (every ray traced to the end), collect_stats == 2 the work of the production path.
+    static const bool exit_enabled = [] { const char *e = std::getenv("RTK_SHADOW_EARLY_EXIT"); return !(e && e[0] == '0'); }();
+    A.shadow_exit = (exit_enabled && !a->has_refractive && p->collect_stats != 1) ? 1 : 0;
     RTK_HIP(hipMemsetAsync(a->d_counters, 0, kCounterWords * sizeof(unsigned long long), s));
     if (g.world > 1) {
         // buckets past the end of the frame (padding so that every rank has equal length) stay zero
@@ -535,7 +545,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         if (rc != RTK_OK) return rc;
         A.prim = a->tp_prim; A.bin_count = a->tp_bins; A.n_listed = a->tp_bins + kCostBins; A.bin_list = a->tp_bin_list;
         A.tile_order = a->tp_order; A.tile_cap = uint32_t(a->tp_tiles);
-        const hipError_t et = launch_twopass(A, p->collect_stats != 0, forks, s);
+        const hipError_t et = launch_twopass(A, p->collect_stats != 0, general, s);
         if (et != hipSuccess) return hip_fail(et, "launch two-pass frame");
     } else if (stream) {
         const size_t out_pixels = (g.world > 1) ? size_t(g.buckets_per_rank) * g.bucket * g.bucket : size_t(g.width) * g.height;
@@ -577,7 +587,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         if (ef != hipSuccess) return hip_fail(ef, "launch overflow reset");
         dev::RenderArgs F = A;
         F.only_if = a->ws.ctrl + dev::kCtrlOverflow;
-        ef = launch_render(F, RTK_TRACE_GROUP4, p->collect_stats != 0, forks, s);
+        ef = launch_render(F, RTK_TRACE_GROUP4, p->collect_stats != 0, general, s);
         if (ef != hipSuccess) return hip_fail(ef, "launch fallback k_render");
         if (std::getenv("RTK_STREAM_DEBUG")) {
             uint32_t h[dev::kCtrlWords];
@@ -604,20 +614,29 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
                                      (uint64_t(uint32_t(g.bucket)) << 32) | uint32_t(p->trace_mode)};
             if (a->fb_units != units) {
                 (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
-                a->fb_cost = a->fb_order = nullptr; a->fb_bins = nullptr; a->fb_units = 0; a->fb_valid = false;
+                a->fb_cost = a->fb_order = nullptr; a->fb_bins = nullptr; a->fb_units = 0; a->fb_valid = false; a->fb_order_valid = false;
                 RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_cost), units * sizeof(uint32_t)));
-                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_order), (units + 2) * sizeof(uint32_t)));   // + header
+                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_order), (units + 4) * sizeof(uint32_t)));   // + header
                 RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_bins), units));
                 a->fb_units = units;
             }
-            if (a->fb_valid && std::memcmp(sig, a->fb_sig, sizeof(sig)) == 0) {
-                // blocks that cost less than this many cycles (background, a handful of nodes) are packed four to a workgroup
-                static const uint32_t light_cycles = [] { const char *e = std::getenv("RTK_LIGHT_BELOW_CYCLES"); return e ? uint32_t(std::atol(e)) : 40000u; }();
-                const bool group_mode = p->trace_mode == RTK_TRACE_AUTO || p->trace_mode == RTK_TRACE_GROUP4 ||
-                                        p->trace_mode == RTK_TRACE_GROUP8 || p->trace_mode == RTK_TRACE_GROUP16;
-                const hipError_t eo = launch_order_by_cost(a->fb_cost, a->fb_bins, a->fb_order, a->fb_order + units, uint32_t(units),
-                                                           group_mode ? light_cycles >> 4 : 0u, s);
-                if (eo != hipSuccess) return hip_fail(eo, "launch k_order_by_cost");
+            const bool same_shape = a->fb_valid && std::memcmp(sig, a->fb_sig, sizeof(sig)) == 0;
+            if (!same_shape) a->fb_order_valid = false;
+            if (same_shape) {
+                // The order is refreshed from the newest costs every few frames only: the sort is one small workgroup whose
+                // ~28 us sit in front of the frame, and an order that is a few frames old is as good (costs move slowly).
+                static const unsigned every = [] { const char *e = std::getenv("RTK_COST_RESORT_EVERY"); const int v = e ? std::atoi(e) : 8; return unsigned(v > 0 ? v : 1); }();
+                if (!a->fb_order_valid || a->fb_age >= every) {
+                    // blocks that cost less than this many cycles (background, a handful of nodes) are packed four to a workgroup
+                    static const uint32_t light_cycles = [] { const char *e = std::getenv("RTK_LIGHT_BELOW_CYCLES"); return e ? uint32_t(std::atol(e)) : 40000u; }();
+                    const bool group_mode = p->trace_mode == RTK_TRACE_AUTO || p->trace_mode == RTK_TRACE_GROUP4;   // light packing: GROUP4 only
+                    const hipError_t eo = launch_order_by_cost(a->fb_cost, a->fb_bins, a->fb_order, a->fb_order + units, uint32_t(units),
+                                                               group_mode ? light_cycles >> 4 : 0u, s);
+                    if (eo != hipSuccess) return hip_fail(eo, "launch k_order_by_cost");
+                    a->fb_order_valid = true;
+                    a->fb_age = 0;
+                }
+                a->fb_age += 1;
                 A.order_in = a->fb_order; A.order_hdr = a->fb_order + units;
             }
             A.cost_out = a->fb_cost;
@@ -626,7 +645,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         }
         // RTK_TRACE_AUTO for frames: workgroup-cooperative leaves (fastest megakernel variant on every config scene)
         const hipError_t e = launch_render(A, p->trace_mode == RTK_TRACE_AUTO ? RTK_TRACE_GROUP4 : p->trace_mode,
-                                           p->collect_stats != 0, forks, s);
+                                           p->collect_stats != 0, general, s);
         if (e != hipSuccess) return hip_fail(e, "launch k_render");
     }
     a->last_stream = s;

@@ -96,6 +96,9 @@ template <int MODE, bool STATS, bool FORKS, bool LDS_NODES, int SLICES, bool PRI
 __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : SLICES == 8 ? 2 : (SLICES == 4 && !STATS ? RTK_G4_WAVES : 4)) void k_render(RenderArgs A) {
     // PRIMED (second pass of a two-pass frame): pixel blocks come from tile_order (most expensive first) and the
     // camera ray's hit is read from A.prim instead of being traced again
+#ifdef RTK_DEBUG_PHASES
+    const unsigned long long ph_entry = __builtin_readcyclecounter();
+#endif
     if (PRIMED && blockIdx.x >= *A.n_listed) return;
     if (A.only_if != nullptr && *A.only_if == 0u) return;        // fallback launch behind the streaming pipeline: nothing overflowed
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -141,6 +144,9 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     }
     SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, light ? 0xFFFFFFFFu : A.slice_min_tris, 0u, true, 0u};
     const uint32_t lane = threadIdx.x & 63u;
+    // one parking area per wave that can own rays: every wave of a light or SLICES == 1 workgroup, one otherwise
+    __shared__ float park_lds[4][15][64];                                  // light workgroups exist for SLICES == 4 only (api.hip)
+    const uint32_t park_slot = (SLICES > 1 && !light) ? 0u : (wave_in_wg & 3u);
     const unsigned long long cost_t0 = __builtin_readcyclecounter();
     constexpr bool writer = true;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
@@ -185,6 +191,9 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     Cand cand;
     cand.t = kFltMax; cand.u = cand.v = 0.f; cand.k = kMiss;
     bool primed = false;
+#ifdef RTK_DEBUG_PHASES
+    unsigned long long ph_first_trace = 0, ph_after_first = 0;
+#endif
 
     for (;;) {
         // ---------- resolve: run each lane forward until it needs a ray traced (or is done)
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                     rkey = child_key(rkey, 0u);
                     cull = false; depth += 1; pend = PEND_CHILD_BG;
                     state = ST_TRACE;
-                } else if (kind == RTK_MAT_REFRACTIVE) {                                        // :252-301
+                } else if (FORKS && kind == RTK_MAT_REFRACTIVE) {                               // :252-301 (FORKS = the general kernel)
                     V3 n = normalized(mat->smooth ? hn : fn);
                     const V3 i = normalized(din);
                     float eta_i = 1.0f, eta_r = mat->ior;
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                         state = ST_TRACE;
                     }
                 } else {                                                                        // diffuse :148-209, texture :211-238
-                    lit_textured = (kind == RTK_MAT_TEXTURE);          // light loop only: no GI rays, no final division
+                    lit_textured = FORKS && (kind == RTK_MAT_TEXTURE); // light loop only: no GI rays, no final division
                     if (!lit_textured) albedo = mk(mat->albedo[0], mat->albedo[1], mat->albedo[2]);
                     ncos = mat->smooth ? hn : fn;
                     acc = black;
@@ -371,6 +380,19 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         // ---------- one wave-wide closest-hit query for every lane that has a ray pending
         const bool need = (state == ST_TRACE);
         if (__ballot(need) == 0ull) break;
+        // hn/fn/din/ret are written when a hit (or a miss) is consumed below and read by ST_SHADE / ST_RETURN in the very next
+        // resolve pass, never across a trace.  Saying so keeps twelve registers out of the traversal loops (the difference
+        // between 5 resident waves per SIMD with scratch spills and 5 without).
+        hn = black; fn = black; din = black; ret = black;
+        // State that is live across the query but not used by it waits in LDS instead of in registers: with it the
+        // traversal loops overflow the 96 registers of a 5-waves-per-SIMD build into scratch (measured: a background block
+        // spent more time on scratch reloads than on its rays).  [var][lane] layout: conflict-free, 30 LDS operations per query.
+        float *const park = &park_lds[park_slot][0][lane];
+        park[0 * 64] = pixel_sum.x; park[1 * 64] = pixel_sum.y; park[2 * 64] = pixel_sum.z;
+        park[3 * 64] = acc.x; park[4 * 64] = acc.y; park[5 * 64] = acc.z;
+        park[6 * 64] = albedo.x; park[7 * 64] = albedo.y; park[8 * 64] = albedo.z;
+        park[9 * 64] = ncos.x; park[10 * 64] = ncos.y; park[11 * 64] = ncos.z;
+        park[12 * 64] = P.x; park[13 * 64] = P.y; park[14 * 64] = P.z;
         if (PRIMED && wave_any(primed)) {
             // first iteration of the pass: every pending ray is a camera ray whose hit the first pass already found
             if (need) {
@@ -382,19 +404,26 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         } else {
 #ifdef RTK_DEBUG_PHASES
             const unsigned long long tr0 = __builtin_readcyclecounter();
+            if (ph_first_trace == 0) ph_first_trace = tr0;
 #endif
             // shadow rays of scenes without transmissive materials only ask "is the closest hit nearer than the light":
-            // they may stop at the first hit that says yes (trace(), `exit_t`).  The work counters are the reference's,
-            // so the STATS build traces every ray to the end.
-            const float exit_t = (!STATS && !A.has_refractive && pend == PEND_SHADOW) ? shadow_max_t : -1.0f;
+            // they may stop at the first hit that says yes (trace(), `exit_t`; A.shadow_exit is set by the host).
+            const float exit_t = (A.shadow_exit && pend == PEND_SHADOW) ? shadow_max_t : -1.0f;
             cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx, kAutoMinLanes, exit_t);
 #ifdef RTK_DEBUG_PHASES
             sx.c_trace += __builtin_readcyclecounter() - tr0; sx.n_trace += 1u;
+            if (ph_after_first == 0) ph_after_first = __builtin_readcyclecounter();
 #endif
         }
 #ifdef RTK_DEBUG_WAVE_TIME
         dbg_iters += 1;
 #endif
+
+        pixel_sum = mk(park[0 * 64], park[1 * 64], park[2 * 64]);
+        acc = mk(park[3 * 64], park[4 * 64], park[5 * 64]);
+        albedo = mk(park[6 * 64], park[7 * 64], park[8 * 64]);
+        ncos = mk(park[9 * 64], park[10 * 64], park[11 * 64]);
+        P = mk(park[12 * 64], park[13 * 64], park[14 * 64]);
 
         // ---------- consume
         if (need) {
@@ -426,7 +455,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 P = ray.o + (cand.t * ray.d);                                // kd_tree_simd.hpp:254
                 hn = s.hit_normal; fn = s.face_normal; din = ray.d;
                 hit_tri = s.tri; hit_mat = s.material;
-                if (A.tri_uv != nullptr && A.materials[hit_mat].kind == RTK_MAT_TEXTURE)      // texture_material: colour of this hit
+                if (FORKS && A.tri_uv != nullptr && A.materials[hit_mat].kind == RTK_MAT_TEXTURE)   // texture_material: colour of this hit
                     albedo = sample_texture(A.textures + A.materials[hit_mat].texture, A.tri_uv + hit_tri, cand.u, cand.v);
                 state = ST_SHADE;
             }
@@ -442,10 +471,13 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
 #endif
 #ifdef RTK_DEBUG_PHASES
     if (valid && writer) {
-        const float vals[11] = {(float)(__builtin_readcyclecounter() - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
-                                (float)sx.n_small, (float)sx.t_small, (float)sx.c_small, (float)sx.n_big, (float)sx.t_big, (float)sx.c_big, 0.f};
+        const unsigned long long ph_now = __builtin_readcyclecounter();
+        const float vals[14] = {(float)(ph_now - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
+                                (float)sx.n_small, (float)sx.t_small, (float)sx.c_small, (float)sx.n_big, (float)sx.t_big, (float)sx.c_big,
+                                (float)(ph_begin - ph_entry), (float)(ph_first_trace - ph_begin), (float)(ph_after_first - ph_first_trace),
+                                (float)(ph_now - ph_after_first)};
         float v = 0.f;
-        for (int i = 0; i < 10; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
+        for (int i = 0; i < 14; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
         float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
         o[0] = v; o[1] = 0.f; o[2] = 0.f;
     }
@@ -629,26 +661,65 @@ __global__ __launch_bounds__(1024) void k_order_by_cost(const uint32_t *cost, ui
                                                         uint32_t light_below) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t start[256];
-    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) hist[i] = 0u;
+    const uint32_t light_bin = light_below > 0u ? cost_bin(light_below) : 0u;  // bins below it are "light"
+    constexpr uint32_t kBatch = 8;                                          // loads in flight per thread: the kernel is one workgroup,
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) hist[i] = 0u; // so memory latency, not bandwidth, is what it waits for
     __syncthreads();
     // the bin of every block is computed once and kept: `order` is a permutation even if cost[] changes under us
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t b = cost_bin(cost[i]);
-        bins[i] = (uint8_t)b;
-        atomicAdd(&hist[b], 1u);
+    for (uint32_t base = 0; base < n; base += blockDim.x * kBatch) {
+        uint32_t c[kBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            const uint32_t i = base + k * blockDim.x + threadIdx.x;
+            c[k] = i < n ? cost[i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            const uint32_t i = base + k * blockDim.x + threadIdx.x;
+            // most blocks of a frame are cheap and need no order among themselves: they all go to bin 0, counted once per wave
+            uint32_t b = i < n ? cost_bin(c[k]) : 0u;
+            if (b < light_bin) b = 0u;
+            if (i < n) bins[i] = (uint8_t)b;
+            const unsigned long long cheap = __builtin_amdgcn_ballot_w64(i < n && b == 0u);
+            if (i < n && b != 0u) atomicAdd(&hist[b], 1u);
+            if (cheap != 0ull && (int)__lane_id() == __builtin_ctzll(cheap)) atomicAdd(&hist[0], (uint32_t)__popcll(cheap));
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0u) {
-        uint32_t acc = 0u, n_single = n;
-        const int light_bin = light_below > 0u ? (int)cost_bin(light_below) : 0;       // bins below it are "light"
-        for (int b = 255; b >= 0; --b) {
-            if (b == light_bin - 1) n_single = acc;
-            start[b] = acc; acc += hist[b];
-        }
-        hdr[0] = n_single; hdr[1] = n;                                      // order[0, n_single): one workgroup each; the rest packed
+        uint32_t acc = 0u;
+        for (int b = 255; b >= 0; --b) { start[b] = acc; acc += hist[b]; }
+        hdr[0] = light_bin > 0u ? start[0] : n;                             // order[0, n_single): one workgroup each; the rest packed
+        hdr[1] = n;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&start[bins[i]], 1u)] = i;
+    for (uint32_t base = 0; base < n; base += blockDim.x * kBatch) {
+        uint32_t b[kBatch], pos[kBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            const uint32_t i = base + k * blockDim.x + threadIdx.x;
+            b[k] = i < n ? (uint32_t)bins[i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            const uint32_t i = base + k * blockDim.x + threadIdx.x;
+            const unsigned long long cheap = __builtin_amdgcn_ballot_w64(i < n && b[k] == 0u);
+            pos[k] = 0u;
+            if (i < n && b[k] != 0u) pos[k] = atomicAdd(&start[b[k]], 1u);
+            if (cheap != 0ull) {
+                const int leader = __builtin_ctzll(cheap);
+                uint32_t first = 0u;
+                if ((int)__lane_id() == leader) first = atomicAdd(&start[0], (uint32_t)__popcll(cheap));
+                first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+                if (i < n && b[k] == 0u) pos[k] = first + (uint32_t)__popcll(cheap & ((1ull << __lane_id()) - 1ull));
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBatch; ++k) {
+            const uint32_t i = base + k * blockDim.x + threadIdx.x;
+            if (i < n) order[pos[k]] = i;
+        }
+    }
 }
 }  // namespace dev
 

@@ -69,6 +69,7 @@ struct RenderArgs {
     uint32_t *cost_out;               // [n_units] or null
     const uint32_t *order_in;         // permutation of the pixel blocks, or null = natural order
     const uint32_t *order_hdr;        // {n_single, n}: see launch_order_by_cost
+    int shadow_exit;                  // occlusion queries may stop at the first answering hit (no transmissive material; trace())
 
     __device__ __forceinline__ size_t out_index(uint32_t local_bucket, uint32_t lx, uint32_t ly, uint32_t px,
                                                 uint32_t py) const {

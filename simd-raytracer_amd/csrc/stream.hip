@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         bool clear = true;
         while (wave_any(pending)) {
             // no transmissive material in the scene: the query may stop at the first hit nearer than the light (trace(), `exit_t`)
-            const float exit_t = (!STATS && !A.has_refractive) ? max_t : -1.0f;
+            const float exit_t = A.shadow_exit ? max_t : -1.0f;
             const Cand c = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, false, pending, st, sx, S.auto_min_lanes, exit_t);
             if (pending) {
                 nrays += 1u;
