@@ -39,14 +39,15 @@ def main():
     kernel_sub = sys.argv[2] if len(sys.argv) > 2 else "k_render"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    newest = lambda paths: sorted(paths, key=os.path.getmtime)[-1:]      # gpurun_out/ accumulates runs: take the latest
+    stats = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
     merged, launches, kname = {}, 0, None
     for pass_dir in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if not os.path.isdir(pass_dir):
             continue
-        for path in glob.glob(os.path.join(pass_dir, "*", "*_counter_collection.csv")):
+        for path in newest(glob.glob(os.path.join(pass_dir, "*", "*_counter_collection.csv"))):
             name, means, n = counter_means(path, kernel_sub)
             if name:
                 kname, launches = name, max(launches, n)
