@@ -223,7 +223,7 @@ def main() -> None:
             "config": {"workload": "BASELINE configs[1]: scenes/hw09/scene5.crtscene 1920x1080 1spp max_ray_depth=5 "
                                    "(primary + shadow + reflection rays), kd_tree_simd_accel semantics",
                        "rays_per_frame": int(rays_total), "primary_rays": WIDTH * HEIGHT * SPP,
-                       "trace_mode": TRACE_NAMES[args.trace_mode] + (" (= group4 for this fork-free scene)" if args.trace_mode == 0 else ""), "parallelism": f"bucket-tiles x{world}" + (f", RCCL all-gather of frame k overlapped with render k+1 ({args.pipeline_depth} frames in flight)" if pipe is not None else "")},
+                       "trace_mode": TRACE_NAMES[args.trace_mode] + (" (= group4 megakernel for this fork-free scene; group8 when a rank has < 9000 pixel blocks)" if args.trace_mode == 0 else ""), "parallelism": f"bucket-tiles x{world}" + (f", RCCL all-gather of frame k overlapped with render k+1 ({args.pipeline_depth} frames in flight)" if pipe is not None else "")},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": (traffic or {}).get("hbm_bytes_per_launch"),

@@ -607,6 +607,13 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         static const bool feedback = [] { const char *e = std::getenv("RTK_COST_FEEDBACK"); return !(e && e[0] == '0'); }();
         const size_t units = size_t(g.buckets_per_rank) * g.blocks_side * g.blocks_side;
         A.n_units = uint32_t(units);
+        // RTK_TRACE_AUTO for frames: workgroup-cooperative leaves.  Four waves per pixel block when there are enough blocks
+        // to fill the chip several times over (the frame is then bound by how many blocks run side by side); eight when
+        // there are few (a rank of a sharded frame, a small image: the frame is then as long as its most expensive block,
+        // and eight waves get through its big leaves faster).  Measured on config 2 (tools/rank_times.py): 32,400 blocks
+        // 0.44 ms (GROUP4) vs 0.87 (GROUP8); 4,050 blocks (one rank of eight) 0.43 vs 0.32.
+        static const size_t group8_below = [] { const char *e = std::getenv("RTK_GROUP8_BELOW_BLOCKS"); return e ? size_t(std::atol(e)) : size_t(9000); }();
+        const int frame_mode = p->trace_mode != RTK_TRACE_AUTO ? p->trace_mode : (units < group8_below ? RTK_TRACE_GROUP8 : RTK_TRACE_GROUP4);
         if (feedback && units > 0 && units <= 0x7FFFFFFFull) {
             const uint64_t sig[4] = {(uint64_t(uint32_t(g.width)) << 32) | uint32_t(g.height),
                                      (uint64_t(uint32_t(g.rank)) << 32) | uint32_t(g.world),
@@ -629,7 +636,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
                 if (!a->fb_order_valid || a->fb_age >= every) {
                     // blocks that cost less than this many cycles (background, a handful of nodes) are packed four to a workgroup
                     static const uint32_t light_cycles = [] { const char *e = std::getenv("RTK_LIGHT_BELOW_CYCLES"); return e ? uint32_t(std::atol(e)) : 40000u; }();
-                    const bool group_mode = p->trace_mode == RTK_TRACE_AUTO || p->trace_mode == RTK_TRACE_GROUP4;   // light packing: GROUP4 only
+                    const bool group_mode = frame_mode == RTK_TRACE_GROUP4;                 // light packing: GROUP4 only
                     const hipError_t eo = launch_order_by_cost(a->fb_cost, a->fb_bins, a->fb_order, a->fb_order + units, uint32_t(units),
                                                                group_mode ? light_cycles >> 4 : 0u, s);
                     if (eo != hipSuccess) return hip_fail(eo, "launch k_order_by_cost");
@@ -643,9 +650,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             std::memcpy(a->fb_sig, sig, sizeof(sig));
             a->fb_valid = true;
         }
-        // RTK_TRACE_AUTO for frames: workgroup-cooperative leaves (fastest megakernel variant on every config scene)
-        const hipError_t e = launch_render(A, p->trace_mode == RTK_TRACE_AUTO ? RTK_TRACE_GROUP4 : p->trace_mode,
-                                           p->collect_stats != 0, general, s);
+        const hipError_t e = launch_render(A, frame_mode, p->collect_stats != 0, general, s);
         if (e != hipSuccess) return hip_fail(e, "launch k_render");
     }
     a->last_stream = s;

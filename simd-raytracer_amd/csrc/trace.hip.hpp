@@ -223,9 +223,18 @@ __device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t fi
         const float det = cur.e1x * pvx + cur.e1y * pvy + cur.e1z * pvz;
         unsigned long long m = pass_mask & __builtin_amdgcn_ballot_w64(eps <= (cull ? det : __builtin_fabsf(det)));
         if (m != 0ull) {
-            const float inv_det = (1.0f / det);
             const float tvx = r.o.x - cur.v0x, tvy = r.o.y - cur.v0y, tvz = r.o.z - cur.v0z;
-            const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv_det;
+            const float un = tvx * pvx + tvy * pvy + tvz * pvz;
+            // Most triangles of a leaf are missed by every ray at the `u` test, and the IEEE division that test needs is a
+            // third of the work up to there.  A one-instruction reciprocal estimate (|error| <= 1 ulp) decides the clear
+            // cases first: un*rcp(det) beyond [-1e-30, 1.00001] means the exactly rounded u = un * (1/det) is beyond [0, 1]
+            // as well (the estimate and the exact product differ by < 2^-21 relative; NaNs and a flushed estimate fail both
+            // comparisons and stay in).  Only if some lane is NOT clearly out does the wave run the exact arithmetic.
+            const float u_est = un * __builtin_amdgcn_rcpf(det);
+            m &= ~(__builtin_amdgcn_ballot_w64(u_est < -1.0e-30f) | __builtin_amdgcn_ballot_w64(1.00001f < u_est));
+            if (m == 0ull) { cur = nxt; continue; }
+            const float inv_det = (1.0f / det);
+            const float u = un * inv_det;
             m &= __builtin_amdgcn_ballot_w64(0.0f <= u) & __builtin_amdgcn_ballot_w64(u <= 1.0f);
             if (m != 0ull) {
                 const float qx = tvy * cur.e1z - tvz * cur.e1y;

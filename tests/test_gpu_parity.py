@@ -78,6 +78,46 @@ def test_intersect_matches_oracle(rtk, ora, scene, cull, mode):
     assert np.array_equal(_bits(np.nan_to_num(gn)), _bits(np.nan_to_num(rn)))
 
 
+def _boundary_rays(flat, n, seed):
+    """Rays aimed exactly (to float rounding) at triangle vertices, edge points and a hair outside edges: the barycentric
+    tests 0 <= u, u <= 1, 0 <= v, u + v <= 1 are decided by the last bits.  The wave path settles clear misses with a
+    reciprocal estimate before it runs the IEEE division (trace.hip.hpp); this is where an unsafe shortcut would show."""
+    rng = np.random.default_rng(seed)
+    starts = np.concatenate([[0], np.cumsum(flat.mesh_nverts)[:-1]])
+    tri_mesh = np.repeat(np.arange(len(flat.mesh_ntris)), flat.mesh_ntris)
+    gidx = flat.indices.astype(np.int64) + starts[tri_mesh][:, None]
+    t = rng.integers(0, gidx.shape[0], size=n)
+    v0, v1, v2 = (flat.vertices[gidx[t, k]].astype(np.float64) for k in range(3))
+    kind = rng.integers(0, 5, size=n)
+    a = rng.uniform(0, 1, size=n)
+    eps = np.where(kind == 4, rng.choice([-1.0, 1.0], size=n) * 10.0 ** rng.uniform(-9, -5, size=n), 0.0)
+    bu = np.select([kind == 0, kind == 1, kind == 2, kind >= 3], [np.zeros(n), a, np.zeros(n), a])           # vertex v0 | edge v0v1 | edge v0v2 | edge v1v2
+    bv = np.select([kind == 0, kind == 1, kind == 2, kind >= 3], [np.zeros(n), np.zeros(n) + eps, a, 1.0 - a + eps])
+    target = v0 + bu[:, None] * (v1 - v0) + bv[:, None] * (v2 - v0)
+    origin = target + rng.normal(size=(n, 3)) * rng.uniform(0.5, 30.0, size=(n, 1))
+    d = target - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True) * rng.choice([1.0, 0.37, 4.0], size=(n, 1))
+    return np.ascontiguousarray(np.concatenate([origin, d], axis=1).astype(np.float32))
+
+
+@pytest.mark.parametrize("scene", list(CONFIG_SCENES))
+@pytest.mark.parametrize("cull", [True, False])
+def test_intersect_rays_through_vertices_and_edges(rtk, ora, scene, cull):
+    acc, oacc = _scene_pair(rtk, ora, CONFIG_SCENES[scene])
+    rays = _boundary_rays(oacc.scene.flat, 50_000, seed=len(scene) + int(cull))
+    ref = oacc.intersect(rays, cull)
+    assert (ref["tri"] != 0xFFFFFFFF).sum() > 5000
+    for mode in MODES.values():
+        got = acc.intersect(rays, cull, mode)
+        assert np.array_equal(got["tri"], ref["tri"]), mode
+        for f in ("t", "u", "v"):
+            assert np.array_equal(_bits(got[f]), _bits(ref[f])), (mode, f)
+    # how sharp the set is: a fair share of the hits sit within a few ulps of a barycentric boundary
+    hit = ref["tri"] != 0xFFFFFFFF
+    u, v = ref["u"][hit].astype(np.float64), ref["v"][hit].astype(np.float64)
+    assert (np.minimum(np.minimum(u, v), 1.0 - u - v) < 1e-6).sum() > 500
+
+
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 257, 1000])
 def test_intersect_ragged_sizes(rtk, ora, n):
     acc, oacc = _scene_pair(rtk, ora, SCENE5)
