@@ -75,6 +75,10 @@ struct rtk_accel {
     uint8_t *fb_bins = nullptr;
     size_t fb_units = 0;
     uint64_t fb_sig[4] = {0, 0, 0, 0};
+    // RTK_TRACE_AUTO on forking scenes: which engine is faster for the current shape (render_device_impl)
+    hipEvent_t trial_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t trial_sig[3] = {0, 0, 0};
+    int trial_state = 0;
     bool fb_valid = false;           // fb_cost holds the costs of a frame of shape fb_sig
     bool fb_order_valid = false;     // fb_order was made from such costs
     unsigned fb_age = 0;             // frames rendered with the current order
@@ -412,6 +416,7 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipFree(a->ws.node_bins); (void)hipFree(a->ws.hit_bins); (void)hipFree(a->ws.node_order); (void)hipFree(a->ws.hit_order);
         (void)hipFree(a->tp_prim); (void)hipFree(a->tp_bins); (void)hipFree(a->tp_bin_list); (void)hipFree(a->tp_order);
         (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
+        for (auto &e : a->trial_ev) if (e) (void)hipEventDestroy(e);
     }
     delete a;
 }
@@ -535,7 +540,37 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     // fork-free scenes (no refraction, no GI) can be rendered by the streaming pipeline (stream.hip)
     // RTK_TRACE_AUTO for frames: scenes whose ray trees fork (refraction, diffuse GI) go through the streaming pipeline
     // (all rays of a depth level in parallel); fork-free scenes through the GROUP4 megakernel (fewer launches)
-    const bool stream = p->trace_mode == RTK_TRACE_STREAM || (p->trace_mode == RTK_TRACE_AUTO && forks);
+    // Which of the two wins on a forking scene depends on how much of the frame forks (refractive dragon: pipeline 3x;
+    // a small glass object: megakernel 2x), so RTK_TRACE_AUTO times both on the first frames of a shape and keeps the
+    // faster: frame 1 pipeline, frames 2-3 megakernel (the second one with its cost-feedback order), then the verdict
+    // as soon as the events have completed (hipEventQuery, never a host wait).  Both engines produce the same frame.
+    bool stream = p->trace_mode == RTK_TRACE_STREAM || (p->trace_mode == RTK_TRACE_AUTO && forks);
+    hipEvent_t trial_start = nullptr, trial_end = nullptr;
+    if (p->trace_mode == RTK_TRACE_AUTO && forks && !p->collect_stats) {
+        static const bool trials = [] { const char *e = std::getenv("RTK_AUTO_TRIALS"); return !(e && e[0] == '0'); }();
+        const uint64_t tsig[3] = {(uint64_t(uint32_t(g.width)) << 32) | uint32_t(g.height), (uint64_t(uint32_t(g.rank)) << 32) | uint32_t(g.world),
+                                  (uint64_t(uint32_t(p->spp)) << 32) | (uint64_t(uint32_t(p->max_ray_depth)) << 16) | uint32_t(p->diffuse_rays)};
+        if (std::memcmp(tsig, a->trial_sig, sizeof(tsig)) != 0) { std::memcpy(a->trial_sig, tsig, sizeof(tsig)); a->trial_state = 0; }
+        if (trials) {
+            if (!a->trial_ev[0]) for (auto &e : a->trial_ev) RTK_HIP(hipEventCreate(&e));
+            if (a->trial_state == 3) {                                      // both timed: is the verdict in?
+                float t_stream = 0.f, t_mega = 0.f;
+                if (hipEventQuery(a->trial_ev[1]) == hipSuccess && hipEventQuery(a->trial_ev[3]) == hipSuccess &&
+                    hipEventElapsedTime(&t_stream, a->trial_ev[0], a->trial_ev[1]) == hipSuccess &&
+                    hipEventElapsedTime(&t_mega, a->trial_ev[2], a->trial_ev[3]) == hipSuccess)
+                    a->trial_state = t_mega < t_stream ? 5 : 4;
+                else (void)hipGetLastError();                               // not ready yet: clear the sticky "not ready"
+            }
+            switch (a->trial_state) {
+                case 0: stream = true; trial_start = a->trial_ev[0]; trial_end = a->trial_ev[1]; a->trial_state = 1; break;
+                case 1: stream = false; a->trial_state = 2; break;          // first megakernel frame: records the block costs
+                case 2: stream = false; trial_start = a->trial_ev[2]; trial_end = a->trial_ev[3]; a->trial_state = 3; break;
+                case 5: stream = false; break;
+                default: stream = true; break;                              // 3 (waiting for the events), 4 (pipeline won)
+            }
+        }
+    }
+    if (trial_start) RTK_HIP(hipEventRecord(trial_start, s));
     const bool twopass = p->trace_mode == RTK_TRACE_TWOPASS;
     if (twopass && p->spp != 1) return fail(RTK_ERR_UNSUPPORTED, "RTK_TRACE_TWOPASS needs spp == 1");
     if (twopass) {
@@ -653,6 +688,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         const hipError_t e = launch_render(A, frame_mode, p->collect_stats != 0, general, s);
         if (e != hipSuccess) return hip_fail(e, "launch k_render");
     }
+    if (trial_end) RTK_HIP(hipEventRecord(trial_end, s));
     a->last_stream = s;
     a->last_stats = p->collect_stats != 0;
     // primary rays of this rank: pixels of its buckets x spp

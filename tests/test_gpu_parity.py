@@ -327,6 +327,19 @@ def test_early_exit_occlusion_queries_change_the_work_not_the_frame(rtk, ora, mo
     assert out[2]["tris"] < out[1]["tris"] and out[2]["nodes"] <= out[1]["nodes"]
 
 
+@pytest.mark.parametrize("scene,depth,gi", [("scene8", 10, 0), ("hw15_scene2", 5, 1)])
+def test_auto_engine_trials_on_forking_scenes_keep_the_frame(rtk, ora, scene, depth, gi):
+    """RTK_TRACE_AUTO on a scene whose ray trees fork times the streaming pipeline and the megakernel on the first frames of
+    a shape and keeps the faster (api.hip).  Whichever engine a frame goes through, it is the oracle's frame."""
+    acc, oacc = _scene_pair(rtk, ora, CONFIG_SCENES[scene])
+    ref, ocn = oacc.render(240, 136, 2, depth, gi)
+    cfg = rtk.RenderConfig(width=240, height=136, spp=2, max_ray_depth=depth, diffuse_rays=gi)
+    for i in range(8):
+        rgb, cn = acc.render_frame(cfg)
+        assert cn["rays"] == ocn["rays"], i
+        assert np.array_equal(_bits(rgb), _bits(ref)), i
+
+
 def test_streaming_pipeline_queue_overflow_falls_back_to_the_megakernel(rtk, ora, monkeypatch):
     """With room for the camera rays only, every refractive / GI child overflows the node queue: the frame must
     still be exact (redone by the megakernel) and the counters must describe one frame, not two."""

@@ -25,8 +25,9 @@ for cname, (path, kw) in CASES.items():
             acc.render_frame_device(cfg, out.data_ptr(), st)
         except rtk.RtkError as e:
             print(f"{cname:32s} {names[mode]:8s} n/a ({e.code})"); continue
+        for _ in range(7): acc.render_frame_device(cfg, out.data_ptr(), st)   # cost feedback / engine trials settle on the first frames
         torch.cuda.synchronize()
-        n = 5
+        n = 8
         t0 = time.perf_counter()
         for _ in range(n): acc.render_frame_device(cfg, out.data_ptr(), st)
         torch.cuda.synchronize()
