@@ -248,9 +248,9 @@ class Scene:
         _check(_L.rtk_scene_vertex_normals(self._h, mesh, out.ctypes.data))
         return out
 
-    def __del__(self):
+    def __del__(self, _destroy=_L.rtk_scene_destroy):     # bound at definition: module globals may be gone at interpreter exit
         if getattr(self, "_h", None):
-            _L.rtk_scene_destroy(self._h)
+            _destroy(self._h)
             self._h = None
 
 
@@ -362,9 +362,9 @@ class KdTreeSimdAccel:
         p = cfg.to_c()
         _check(_L.rtk_tiles_assemble_device(self._h, C.byref(p), d_gathered_ptr, d_rgb_ptr, stream))
 
-    def __del__(self):
+    def __del__(self, _destroy=_L.rtk_accel_destroy):
         if getattr(self, "_h", None):
-            _L.rtk_accel_destroy(self._h)
+            _destroy(self._h)
             self._h = None
 
 
