@@ -45,7 +45,9 @@ enum { RTK_TEX_ALBEDO = 0, RTK_TEX_EDGES = 1, RTK_TEX_CHECKER = 2 };
 /* traversal strategy of the device kernels; all of them give bit-identical results */
 enum {
     RTK_TRACE_AUTO = 0,   /* batched intersect: wave-cooperative while the wave's rays agree, per-lane otherwise;
-                             frames: RTK_TRACE_STREAM when the scene's ray trees fork (refraction, diffuse GI), else RTK_TRACE_GROUP4 */
+                             frames: the GROUP4 megakernel (GROUP8 when the frame has few pixel blocks); scenes whose ray trees
+                             fork (refraction, diffuse GI) are timed through RTK_TRACE_STREAM and the megakernel on their first
+                             frames and keep the faster */
     RTK_TRACE_LANE = 1,   /* one ray per lane, independent stackless traversal */
     RTK_TRACE_WAVE = 2,   /* one wave walks the tree once for its 64 rays (scalar node/triangle fetch) */
     RTK_TRACE_GROUP4 = 3, /* frames only: 4 waves share 64 rays and split every large leaf 4 ways (merge through LDS) */

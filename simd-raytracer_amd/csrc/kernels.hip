@@ -91,8 +91,8 @@ struct Frame {            // 15 dwords, lives in scratch; touched only at refrac
 };
 
 template <int MODE, bool STATS, bool FORKS, bool LDS_NODES, int SLICES, bool PRIMED = false>
-// GROUP4 without per-ray statistics is built for RTK_G4_WAVES (5) waves per SIMD: 96 VGPRs and a 48-byte spill buy a
-// fifth resident workgroup per CU (measured 0.912 -> 0.881 ms on config 2; 6 waves / 80 VGPRs gives no more)
+// GROUP4 without per-ray statistics is built for RTK_G4_WAVES (5) waves per SIMD = 96 VGPRs: a fifth resident workgroup per CU.
+// The lean build (FORKS = false) fits with its cold state parked in LDS (`park_lds`); 4 waves / 128 VGPRs and 6 / 80 are slower.
 __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : SLICES == 8 ? 2 : (SLICES == 4 && !STATS ? RTK_G4_WAVES : 4)) void k_render(RenderArgs A) {
     // PRIMED (second pass of a two-pass frame): pixel blocks come from tile_order (most expensive first) and the
     // camera ray's hit is read from A.prim instead of being traced again
