@@ -1,14 +1,25 @@
 """Generated scenes through the C-ABI scene constructor (rtk_scene_create) against the oracle: triangle soups, a bumpy height
 field, axis-aligned quads (rays parallel to box planes -> inf / NaN slabs), zero-area and duplicated triangles, all four
 material kinds and textures, several lights, a light exactly on a surface.  Frames must be bit-identical through every engine."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+N_SEEDS = int(os.environ.get("RTK_SOAK_SEEDS", "8"))      # a soak run sets this to a few hundred
 
 
 def _bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _same_frame(a, b):
+    """Bit-identical, except that a NaN pixel (a light sitting exactly on a surface divides by a zero distance) only has to be a
+    NaN on both sides: which payload and sign a NaN carries through an addition is a property of the hardware (x86 SSE keeps the
+    first operand's, its default NaN is negative; the GPU's is positive), not of the algorithm."""
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and np.array_equal(_bits(np.where(na, 0.0, a).astype(np.float32)), _bits(np.where(nb, 0.0, b).astype(np.float32)))
 
 
 def _make_scene(ora, seed):
@@ -64,7 +75,7 @@ def _rtk_scene(rtk, f):
                                  f.width, f.height, f.bucket_size)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_generated_scenes_render_bit_exactly(rtk, ora, seed):
     flat = _make_scene(ora, seed)
     acc = rtk.KdTreeSimdAccel(_rtk_scene(rtk, flat))
@@ -77,7 +88,7 @@ def test_generated_scenes_render_bit_exactly(rtk, ora, seed):
         for rep in range(2):                                                   # the second frame runs in cost-feedback order
             rgb, cn = acc.render_frame(rtk.RenderConfig(width=96, height=64, spp=spp, max_ray_depth=4, diffuse_rays=gi, trace_mode=mode))
             assert cn["rays"] == ocn["rays"], (mode, rep)
-            assert np.array_equal(_bits(rgb), _bits(ref)), (mode, rep)
+            assert _same_frame(rgb, ref), (mode, rep)
 
 
 @pytest.mark.parametrize("seed", range(3))
