@@ -201,57 +201,65 @@ __device__ __forceinline__ TriS load_tri_uniform(cptr_f32 tp) {
     return t;
 }
 
+// one triangle against the wave's rays (the arithmetic of test_triangle, wave-level early outs between the stages)
+__device__ __forceinline__ void tri_step(const TriS &cur, const uint32_t k, const Ray &r, const bool cull, const float eps,
+                                         const unsigned long long pass_mask, const uint32_t lane, Cand &best) {
+    const float pvx = r.d.y * cur.e2z - r.d.z * cur.e2y;
+    const float pvy = r.d.z * cur.e2x - r.d.x * cur.e2z;
+    const float pvz = r.d.x * cur.e2y - r.d.y * cur.e2x;
+    const float det = cur.e1x * pvx + cur.e1y * pvy + cur.e1z * pvz;
+    unsigned long long m = pass_mask & __builtin_amdgcn_ballot_w64(eps <= (cull ? det : __builtin_fabsf(det)));
+    if (m == 0ull) return;
+    const float tvx = r.o.x - cur.v0x, tvy = r.o.y - cur.v0y, tvz = r.o.z - cur.v0z;
+    const float un = tvx * pvx + tvy * pvy + tvz * pvz;
+    // Most triangles of a leaf are missed by every ray at the `u` test, and the IEEE division that test needs is a
+    // third of the work up to there.  A one-instruction reciprocal estimate (|error| <= 1 ulp) decides the clear
+    // cases first: un*rcp(det) beyond [-1e-30, 1.00001] means the exactly rounded u = un * (1/det) is beyond [0, 1]
+    // as well (the estimate and the exact product differ by < 2^-21 relative; NaNs and a flushed estimate fail both
+    // comparisons and stay in).  Only if some lane is NOT clearly out does the wave run the exact arithmetic.
+    const float u_est = un * __builtin_amdgcn_rcpf(det);
+    m &= ~(__builtin_amdgcn_ballot_w64(u_est < -1.0e-30f) | __builtin_amdgcn_ballot_w64(1.00001f < u_est));
+    if (m == 0ull) return;
+    const float inv_det = (1.0f / det);
+    const float u = un * inv_det;
+    m &= __builtin_amdgcn_ballot_w64(0.0f <= u) & __builtin_amdgcn_ballot_w64(u <= 1.0f);
+    if (m == 0ull) return;
+    const float qx = tvy * cur.e1z - tvz * cur.e1y;
+    const float qy = tvz * cur.e1x - tvx * cur.e1z;
+    const float qz = tvx * cur.e1y - tvy * cur.e1x;
+    const float v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv_det;
+    m &= __builtin_amdgcn_ballot_w64(0.0f <= v) & __builtin_amdgcn_ballot_w64(u + v <= 1.0f);
+    if (m == 0ull) return;
+    const float t = (cur.e2x * qx + cur.e2y * qy + cur.e2z * qz) * inv_det;
+    m &= __builtin_amdgcn_ballot_w64(eps < t) & __builtin_amdgcn_ballot_w64(t < best.t);
+    if (m == 0ull) return;
+    if ((m >> lane) & 1ull) { best.t = t; best.u = u; best.v = v; best.k = k; }
+}
+
 // Tests leaf references [lo, hi) of the leaf starting at `first` against the wave's rays (lanes with `pass`).
-// Software-pipelined: the scalar loads of triangle k+1 are issued before triangle k is tested, so scalar-cache /
-// L2 latency overlaps the arithmetic.  Same arithmetic as test_triangle, with wave-level early outs between stages.
+// Software-pipelined: the scalar loads of the next triangle are issued before the current one is tested, so scalar-cache /
+// L2 latency overlaps the arithmetic.
 __device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t first, const uint32_t lo, const uint32_t hi,
                                                 const Ray &r, const bool cull, const float eps, const bool pass, Cand &best) {
     if (lo >= hi) return;
     // The per-lane predicate of the reference's mask (`mask &= ...`, kd_tree_simd.hpp:33-57) is carried as a 64-bit
     // wave mask in SGPRs: every comparison is one v_cmp writing a lane mask, the ANDs and the "is anybody left"
-    // early-outs run on the scalar unit.
+    // early-outs run on the scalar unit.  Two triangles per turn, A and B: each is fetched into its own registers while
+    // the other is tested, so nothing has to be moved from a "next" set into a "current" one.
     const unsigned long long pass_mask = __builtin_amdgcn_ballot_w64(pass);
     const uint32_t lane = __lane_id();
-    cptr_f32 tp = tris + ((size_t)first + lo) * 9;
-    TriS cur = load_tri_uniform(tp);
-    for (uint32_t k = lo; k < hi; ++k) {
-        if (k + 1u < hi) tp += 9;                                          // last iteration re-reads itself (stays in bounds)
-        const TriS nxt = load_tri_uniform(tp);
-        const float pvx = r.d.y * cur.e2z - r.d.z * cur.e2y;
-        const float pvy = r.d.z * cur.e2x - r.d.x * cur.e2z;
-        const float pvz = r.d.x * cur.e2y - r.d.y * cur.e2x;
-        const float det = cur.e1x * pvx + cur.e1y * pvy + cur.e1z * pvz;
-        unsigned long long m = pass_mask & __builtin_amdgcn_ballot_w64(eps <= (cull ? det : __builtin_fabsf(det)));
-        if (m != 0ull) {
-            const float tvx = r.o.x - cur.v0x, tvy = r.o.y - cur.v0y, tvz = r.o.z - cur.v0z;
-            const float un = tvx * pvx + tvy * pvy + tvz * pvz;
-            // Most triangles of a leaf are missed by every ray at the `u` test, and the IEEE division that test needs is a
-            // third of the work up to there.  A one-instruction reciprocal estimate (|error| <= 1 ulp) decides the clear
-            // cases first: un*rcp(det) beyond [-1e-30, 1.00001] means the exactly rounded u = un * (1/det) is beyond [0, 1]
-            // as well (the estimate and the exact product differ by < 2^-21 relative; NaNs and a flushed estimate fail both
-            // comparisons and stay in).  Only if some lane is NOT clearly out does the wave run the exact arithmetic.
-            const float u_est = un * __builtin_amdgcn_rcpf(det);
-            m &= ~(__builtin_amdgcn_ballot_w64(u_est < -1.0e-30f) | __builtin_amdgcn_ballot_w64(1.00001f < u_est));
-            if (m == 0ull) { cur = nxt; continue; }
-            const float inv_det = (1.0f / det);
-            const float u = un * inv_det;
-            m &= __builtin_amdgcn_ballot_w64(0.0f <= u) & __builtin_amdgcn_ballot_w64(u <= 1.0f);
-            if (m != 0ull) {
-                const float qx = tvy * cur.e1z - tvz * cur.e1y;
-                const float qy = tvz * cur.e1x - tvx * cur.e1z;
-                const float qz = tvx * cur.e1y - tvy * cur.e1x;
-                const float v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv_det;
-                m &= __builtin_amdgcn_ballot_w64(0.0f <= v) & __builtin_amdgcn_ballot_w64(u + v <= 1.0f);
-                if (m != 0ull) {
-                    const float t = (cur.e2x * qx + cur.e2y * qy + cur.e2z * qz) * inv_det;
-                    m &= __builtin_amdgcn_ballot_w64(eps < t) & __builtin_amdgcn_ballot_w64(t < best.t);
-                    if (m != 0ull) {
-                        if ((m >> lane) & 1ull) { best.t = t; best.u = u; best.v = v; best.k = first + k; }
-                    }
-                }
-            }
-        }
-        cur = nxt;
+    cptr_f32 base = tris + (size_t)first * 9;
+    const uint32_t last = hi - 1u;                                         // a prefetch past the range re-reads its last triangle
+    uint32_t k = lo;
+    TriS A = load_tri_uniform(base + (size_t)k * 9);
+    for (;;) {
+        const TriS B = load_tri_uniform(base + (size_t)(k + 1u < hi ? k + 1u : last) * 9);
+        tri_step(A, first + k, r, cull, eps, pass_mask, lane, best);
+        if (k + 1u >= hi) break;
+        A = load_tri_uniform(base + (size_t)(k + 2u < hi ? k + 2u : last) * 9);
+        tri_step(B, first + k + 1u, r, cull, eps, pass_mask, lane, best);
+        if (k + 2u >= hi) break;
+        k += 2u;
     }
 }
 
