@@ -135,6 +135,8 @@ def _lib(fast: bool = False, isa: str | None = None):
     L.ora_intersect.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp]
     L.ora_render_frame.restype = C.c_int
     L.ora_render_frame.argtypes = [vp, C.POINTER(_RenderParams), vp, vp]
+    L.ora_camera_rays.restype = C.c_int
+    L.ora_camera_rays.argtypes = [vp, C.POINTER(_RenderParams), C.c_int, vp]
     L.ora_write_ppm.restype = C.c_size_t
     L.ora_write_ppm.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
     L.ora_root_key.restype = C.c_uint32
@@ -389,6 +391,16 @@ class Accel:
         if rc != 0:
             raise ValueError("ora_render_frame: bad parameters")
         return rgb, dict(zip(COUNTER_NAMES, (int(x) for x in cn)))
+
+    def camera_rays(self, width=0, height=0, spp=1, seed=42, fov_degrees=90.0, sample=0) -> np.ndarray:
+        """[h, w, 6] origin + direction of every pixel's camera ray (render.hpp:35-62)."""
+        p = _RenderParams(width, height, spp, 5, 0, seed, fov_degrees, np.float32(1e-4), np.float32(1e-4), np.float32(1e-4), 1, 0)
+        w = width or self.scene.flat.width
+        h = height or self.scene.flat.height
+        rays = np.zeros((h, w, 6), np.float32)
+        if self.L.ora_camera_rays(self.h, C.byref(p), sample, rays.ctypes.data) != 0:
+            raise ValueError("ora_camera_rays: bad parameters")
+        return rays
 
     def __del__(self):
         try:

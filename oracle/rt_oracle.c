@@ -645,7 +645,7 @@ typedef struct {
     ora_render_params p;
     int width, height;
     float aspect;
-    double tan_half_fov;
+    float tan_half_fov;
     float *rgb;
     /* tile scheduling (tile/bucket.hpp:7-21 + tile/queue.hpp:30-41, as an atomic cursor) */
     int tiles_x, tiles_y, bucket;
@@ -803,33 +803,39 @@ static col color_hit(const frame_ctx *f, thread_ctx *tc, const hit_rec *hr, int 
     }
 }
 
+/* The camera ray of pixel (x, y), render.hpp:35-62; `key` is the sample's root key (draws 0 and 1 jitter the sample). */
+static ray3 camera_ray(const frame_ctx *f, int x, int y, uint32_t key) {
+    const ora_scene *sc = f->accel->scene;
+    const float *M = sc->cam_mat;
+    float rx = (float)x, ry = (float)y;                                    /* :37-38 size_t -> F */
+    if (f->p.spp == 1) { rx += 0.5f; ry += 0.5f; }
+    else { rx += ora_urand_key(key, 0u); ry += ora_urand_key(key, 1u); }
+    const float ndc_x = rx / (float)f->width;                              /* :47-48 F / size_t: the size_t converts to F */
+    const float ndc_y = ry / (float)f->height;
+    float sx = (2.0f * ndc_x) - 1.0f;
+    float sy = 1.0f - (2.0f * ndc_y);
+    sx *= f->aspect;
+    sx *= f->tan_half_fov;                                                 /* :55-57 float *= tanf(float) */
+    sy *= f->tan_half_fov;
+    /* transpose(camera.matrix) * (sx, sy, -1)  (mat3.hpp:34-41, :53-60) */
+    v3 d = mk(M[0] * sx + M[3] * sy + M[6] * -1.0f,
+              M[1] * sx + M[4] * sy + M[7] * -1.0f,
+              M[2] * sx + M[5] * sy + M[8] * -1.0f);
+    d = norm3(d);
+    return mkray(sc->cam_pos, d);
+}
+
 /* render.hpp:30-77 */
 static void render_tile(frame_ctx *f, thread_ctx *tc, int x0, int y0, int x1, int y1) {
     const ora_scene *sc = f->accel->scene;
     const col background = mkcol(sc->background[0], sc->background[1], sc->background[2]);
-    const float *M = sc->cam_mat;
     for (int y = y0; y < y1; ++y) {
         for (int x = x0; x < x1; ++x) {
             col final = mkcol(0.f, 0.f, 0.f);
             const uint32_t pixel = (uint32_t)y * (uint32_t)f->width + (uint32_t)x;
             for (int s = 0; s < f->p.spp; ++s) {
                 const uint32_t key = ora_root_key(f->p.seed, pixel, (uint32_t)s);
-                float rx = (float)x, ry = (float)y;
-                if (f->p.spp == 1) { rx += 0.5f; ry += 0.5f; }
-                else { rx += ora_urand_key(key, 0u); ry += ora_urand_key(key, 1u); }
-                const float ndc_x = rx / (float)f->width;
-                const float ndc_y = ry / (float)f->height;
-                float sx = (2.0f * ndc_x) - 1.0f;
-                float sy = 1.0f - (2.0f * ndc_y);
-                sx *= f->aspect;
-                sx = (float)((double)sx * f->tan_half_fov);               /* :55-57 float *= double */
-                sy = (float)((double)sy * f->tan_half_fov);
-                /* transpose(camera.matrix) * (sx, sy, -1)  (mat3.hpp:34-41, :53-60) */
-                v3 d = mk(M[0] * sx + M[3] * sy + M[6] * -1.0f,
-                          M[1] * sx + M[4] * sy + M[7] * -1.0f,
-                          M[2] * sx + M[5] * sy + M[8] * -1.0f);
-                d = norm3(d);
-                const ray3 ray = mkray(sc->cam_pos, d);
+                const ray3 ray = camera_ray(f, x, y, key);
                 tc->cn[ORA_C_PRIMARY] += 1;
                 hit_rec h;
                 if (accel_intersect(f->accel, &ray, 1, &h, tc->cn)) final = cadd(final, color_hit(f, tc, &h, 0, key));
@@ -859,16 +865,38 @@ static void *worker(void *argp) {
     return NULL;
 }
 
+static int frame_setup(frame_ctx *f, const ora_accel *a, const ora_render_params *p) {
+    memset(f, 0, sizeof(*f));
+    f->accel = a; f->p = *p;
+    f->width = p->width > 0 ? p->width : a->scene->width;
+    f->height = p->height > 0 ? p->height : a->scene->height;
+    if (f->width <= 0 || f->height <= 0 || p->spp < 1) return -1;
+    f->aspect = (float)f->width / (float)f->height;                        /* render.hpp:26 */
+    /* render.hpp:55-57: degrees_to_radians(fov_degrees) runs in double (utils/convert.hpp:4-6, fov_degrees is a double
+     * constant) and is rounded to float by `const F fov_radians`; std::tan(fov_radians / F(2)) is the float overload. */
+    const float fov_radians = (float)(p->fov_degrees * (3.14159265358979323846 / 180.0));
+    f->tan_half_fov = tanf(fov_radians / 2.0f);
+    return 0;
+}
+
+/* The camera rays of sample `sample` of every pixel, [h][w] x {origin xyz, direction xyz} (render.hpp:35-62). */
+int ora_camera_rays(const ora_accel *a, const ora_render_params *p, int sample, float *rays) {
+    frame_ctx f;
+    if (frame_setup(&f, a, p) != 0) return -1;
+    for (int y = 0; y < f.height; ++y) {
+        for (int x = 0; x < f.width; ++x) {
+            const uint32_t pixel = (uint32_t)y * (uint32_t)f.width + (uint32_t)x;
+            const ray3 r = camera_ray(&f, x, y, ora_root_key(p->seed, pixel, (uint32_t)sample));
+            float *o = rays + ((size_t)y * (size_t)f.width + (size_t)x) * 6;
+            o[0] = r.origin.x; o[1] = r.origin.y; o[2] = r.origin.z; o[3] = r.direction.x; o[4] = r.direction.y; o[5] = r.direction.z;
+        }
+    }
+    return 0;
+}
+
 int ora_render_frame(const ora_accel *a, const ora_render_params *p, float *rgb, uint64_t *counters) {
     frame_ctx f;
-    memset(&f, 0, sizeof(f));
-    f.accel = a; f.p = *p;
-    f.width = p->width > 0 ? p->width : a->scene->width;
-    f.height = p->height > 0 ? p->height : a->scene->height;
-    if (f.width <= 0 || f.height <= 0 || p->spp < 1) return -1;
-    f.aspect = (float)f.width / (float)f.height;                           /* render.hpp:26 */
-    const double fov_radians = p->fov_degrees * (3.14159265358979323846 / 180.0);   /* utils/convert.hpp:4-6 in double */
-    f.tan_half_fov = tan(fov_radians / (double)2.0f);
+    if (frame_setup(&f, a, p) != 0) return -1;
     f.rgb = rgb;
     f.bucket = a->scene->bucket_size > 0 ? a->scene->bucket_size : 64;
     f.tiles_x = (f.width + f.bucket - 1) / f.bucket;

@@ -125,6 +125,10 @@ void ora_intersect(const ora_accel *a, const float *rays, size_t n, int cull, or
 int ora_render_frame(const ora_accel *a, const ora_render_params *p, float *rgb,
                      uint64_t *counters /* ORA_C_COUNT, overwritten; may be NULL */);
 
+/* The camera rays render_frame spawns (render/render.hpp:35-62), sample `sample` of every pixel:
+ * rays [h][w][6] = origin xyz, direction xyz. */
+int ora_camera_rays(const ora_accel *a, const ora_render_params *p, int sample, float *rays);
+
 /* write_ppm (io/image/ppm.hpp:7-25): returns bytes written into buf (or needed if buf==NULL). */
 size_t ora_write_ppm(const float *rgb, int width, int height, char *buf, size_t cap);
 

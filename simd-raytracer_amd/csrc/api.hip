@@ -44,7 +44,48 @@ int upload(const std::vector<T> &src, T **dst) {
 }  // namespace
 }  // namespace rtk
 
+// Environment knobs (all optional).  Read ONCE, when an accel is built: nothing on the launch path
+// calls getenv.
+struct rtk_knobs {
+    uint32_t slice_min_tris = rtk::kSliceMinTrisDefault;   // RTK_SLICE_MIN_TRIS
+    bool shadow_exit = true;                                // RTK_SHADOW_EARLY_EXIT
+    bool bundle_cull = true;                                // RTK_BUNDLE_CULL
+    bool auto_trials = true;                                // RTK_AUTO_TRIALS
+    bool cost_feedback = true;                              // RTK_COST_FEEDBACK
+    unsigned resort_every = 8;                              // RTK_COST_RESORT_EVERY
+    uint32_t light_cycles = 40000u;                         // RTK_LIGHT_BELOW_CYCLES
+    size_t group8_below = 9000;                             // RTK_GROUP8_BELOW_BLOCKS
+    int stream_node_factor = 0;                             // RTK_STREAM_NODE_FACTOR (0 = default)
+    int stream_deep_level = 99, stream_deep_mode = RTK_TRACE_AUTO;   // RTK_STREAM_DEEP_LEVEL / _MODE
+    uint32_t auto_min_lanes = 12;                           // RTK_AUTO_MIN_LANES
+    int stream_sort_from = -1;                              // RTK_STREAM_SORT_FROM (-1 = default)
+    bool stream_debug = false;                              // RTK_STREAM_DEBUG
+
+    static rtk_knobs from_env() {
+        rtk_knobs k;
+        auto geti = [](const char *name, long &out) { const char *e = std::getenv(name); if (!e || !*e) return false; out = std::atol(e); return true; };
+        long v;
+        if (geti("RTK_SLICE_MIN_TRIS", v) && v > 0) k.slice_min_tris = uint32_t(v);
+        if (geti("RTK_SHADOW_EARLY_EXIT", v)) k.shadow_exit = v != 0;
+        if (geti("RTK_BUNDLE_CULL", v)) k.bundle_cull = v != 0;
+        if (geti("RTK_AUTO_TRIALS", v)) k.auto_trials = v != 0;
+        if (geti("RTK_COST_FEEDBACK", v)) k.cost_feedback = v != 0;
+        if (geti("RTK_COST_RESORT_EVERY", v) && v > 0) k.resort_every = unsigned(v);
+        if (geti("RTK_LIGHT_BELOW_CYCLES", v) && v >= 0) k.light_cycles = uint32_t(v);
+        if (geti("RTK_GROUP8_BELOW_BLOCKS", v) && v >= 0) k.group8_below = size_t(v);
+        if (geti("RTK_STREAM_NODE_FACTOR", v) && v >= 1) k.stream_node_factor = int(v);
+        if (geti("RTK_STREAM_DEEP_LEVEL", v)) k.stream_deep_level = int(v);
+        if (geti("RTK_STREAM_DEEP_MODE", v)) k.stream_deep_mode = int(v);
+        if (geti("RTK_AUTO_MIN_LANES", v) && v > 0 && v <= 64) k.auto_min_lanes = uint32_t(v);
+        if (geti("RTK_STREAM_SORT_FROM", v)) k.stream_sort_from = int(v);
+        if (geti("RTK_STREAM_DEBUG", v)) k.stream_debug = v != 0;
+        return k;
+    }
+};
+
 struct rtk_accel {
+    rtk_knobs knobs;
+    bool coords_small = false;        // every leaf-reference coordinate is below kBundleLimit: bundle culling cannot overflow
     rtk_scene scene;                  // private copy: the caller may free its scene (kd_tree_simd.hpp:106-107 copies too)
     rtk::HostTree tree;
     rtk_accel_params params;
@@ -53,6 +94,7 @@ struct rtk_accel {
     bool on_device = false;
     int device = -1;
     rtk::DevNode *d_nodes = nullptr;
+    rtk::DevNode *d_leaves = nullptr;
     rtk::DevTri *d_tris = nullptr;
     uint32_t *d_tri_ids = nullptr;
     rtk::DevShade *d_shade = nullptr;
@@ -107,6 +149,7 @@ int ensure_device(rtk_accel *a) {
     a->device = dev;
     int rc;
     if ((rc = upload(a->tree.dev_nodes, &a->d_nodes)) != RTK_OK) return rc;
+    if ((rc = upload(a->tree.dev_leaves, &a->d_leaves)) != RTK_OK) return rc;
     if ((rc = upload(a->tree.dev_tris, &a->d_tris)) != RTK_OK) return rc;
     if ((rc = upload(a->tree.dev_tri_ids, &a->d_tri_ids)) != RTK_OK) return rc;
     if ((rc = upload(a->tree.dev_shade, &a->d_shade)) != RTK_OK) return rc;
@@ -122,26 +165,14 @@ int ensure_device(rtk_accel *a) {
     return RTK_OK;
 }
 
-#ifdef RTK_DEBUG_KHIST
-static unsigned long long *g_khist = nullptr;
-extern "C" void rtk_debug_khist(unsigned long long *out64) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(out64, g_khist, 64 * 8, hipMemcpyDeviceToHost);
-    (void)hipMemset(g_khist, 0, 64 * 8);
-}
-#endif
 dev::TreeView tree_view(const rtk_accel *a) {
     dev::TreeView t;
     t.nodes = a->d_nodes; t.tris = a->d_tris; t.tri_ids = a->d_tri_ids; t.shade = a->d_shade;
+    t.leaves = a->d_leaves; t.n_leaves = static_cast<uint32_t>(a->tree.dev_leaves.size());
     t.n_nodes = static_cast<uint32_t>(a->tree.dev_nodes.size());
     t.eps = a->params.eps;
     t.normalize = a->params.normalize_hit_normal;
-#ifdef RTK_DEBUG_KHIST
-    static unsigned long long *khist = nullptr;
-    if (!khist) { (void)hipMalloc(reinterpret_cast<void **>(&khist), 64 * 8); (void)hipMemset(khist, 0, 64 * 8); }
-    t.khist = khist;
-    g_khist = khist;
-#endif
+    t.bundle_cull = (a->knobs.bundle_cull && a->coords_small) ? 1 : 0;
     return t;
 }
 
@@ -366,7 +397,18 @@ int rtk_accel_build(const rtk_scene *scene, const rtk_accel_params *params, rtk_
         if (a->tree.dev_nodes.size() > 0x7FFFFFFFull || a->tree.dev_tris.size() > 0x7FFFFFFFull) {
             delete a; return fail(RTK_ERR_INVALID, "tree too large for 32-bit node/triangle indices");
         }
+        // eps: the reciprocal-estimate prefilter of tri_step and the bundle culling both assume that a determinant which
+        // passes `eps <= |det|` is a normal float with a finite reciprocal
+        if (!(a->params.eps >= 1.17549435e-38f && a->params.eps < 1.0f)) {
+            delete a; return fail(RTK_ERR_INVALID, "eps must be in [FLT_MIN, 1)");
+        }
         for (const DevMaterial &m : a->scene.materials) if (m.kind == RTK_MAT_REFRACTIVE) a->has_refractive = true;
+        a->knobs = rtk_knobs::from_env();
+        a->coords_small = true;
+        for (const DevTri &t : a->tree.dev_tris)
+            for (int k = 0; k < 3; ++k)
+                if (!(std::fabs(t.v0[k]) <= dev::kBundleLimit && std::fabs(t.e1[k]) <= dev::kBundleLimit && std::fabs(t.e2[k]) <= dev::kBundleLimit))
+                    a->coords_small = false;
         *out = a;
         return RTK_OK;
     } catch (const std::exception &e) { return fail(RTK_ERR_INVALID, e.what()); }
@@ -408,7 +450,7 @@ void rtk_accel_destroy(rtk_accel *a) {
     if (!a) return;
     if (a->on_device) {
         (void)hipSetDevice(a->device);
-        (void)hipFree(a->d_nodes); (void)hipFree(a->d_tris); (void)hipFree(a->d_tri_ids); (void)hipFree(a->d_shade);
+        (void)hipFree(a->d_nodes); (void)hipFree(a->d_leaves); (void)hipFree(a->d_tris); (void)hipFree(a->d_tri_ids); (void)hipFree(a->d_shade);
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
         (void)hipFree(a->d_textures); (void)hipFree(a->d_tri_uv);
         (void)hipFree(a->ws.rays); (void)hipFree(a->ws.nodes); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
@@ -512,16 +554,18 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     std::memcpy(A.background, a->scene.background, sizeof(A.background));
     A.width = g.width; A.height = g.height;
     A.aspect = static_cast<float>(g.width) / static_cast<float>(g.height);                    // render.hpp:26
-    const double fov_radians = p->fov_degrees * (3.14159265358979323846 / 180.0);             // utils/convert.hpp:4-6
-    A.tan_half_fov = std::tan(fov_radians / static_cast<double>(2.0f));                       // render.hpp:55-57
+    // render.hpp:55-57: `const F fov_radians = degrees_to_radians(fov_degrees)` is evaluated in double (fov_degrees is a
+    // double constant, utils/convert.hpp:4-6) and ROUNDED TO FLOAT by the declaration; `std::tan(fov_radians / F(2))` is
+    // then the float overload (tanf), and `screen_x *=` a float multiply (common.hip.hpp camera_ray).
+    const float fov_radians = static_cast<float>(p->fov_degrees * (3.14159265358979323846 / 180.0));
+    A.tan_half_fov = std::tan(fov_radians / 2.0f);
     A.spp = p->spp; A.max_depth = p->max_ray_depth; A.diffuse_rays = p->diffuse_rays; A.seed = p->seed;
     A.shadow_bias = p->shadow_bias; A.reflection_bias = p->reflection_bias; A.refraction_bias = p->refraction_bias;
     A.bucket = g.bucket; A.tiles_x = g.tiles_x; A.tiles_y = g.tiles_y; A.n_buckets = g.n_buckets;
     A.blocks_per_bucket_side = g.blocks_side; A.buckets_per_rank = g.buckets_per_rank;
     A.rank = g.rank; A.world = g.world; A.compact = g.world > 1 ? 1 : 0;
     A.out = d_out; A.counters = a->d_counters;
-    A.slice_min_tris = kSliceMinTrisDefault;
-    if (const char *e = std::getenv("RTK_SLICE_MIN_TRIS")) { const int v = std::atoi(e); if (v > 0) A.slice_min_tris = uint32_t(v); }
+    A.slice_min_tris = a->knobs.slice_min_tris;
     const bool forks = a->has_refractive || p->diffuse_rays > 0;
     // the megakernel comes in two builds: the lean one (diffuse / reflective / constant materials only) and the general one
     // (template FORKS: + refraction, diffuse GI, textures), so that the lean one does not carry the general one's registers
@@ -529,8 +573,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     // Occlusion queries (is_occluded) may stop at the first hit nearer than the light when no material is transmissive: the
     // frame is bit-identical (trace.hip.hpp, `exit_t`), only the per-ray work counters shrink.  collect_stats == 1 counts the
     // reference's work (every ray traced to the end), collect_stats == 2 the work of the production path.
-    static const bool exit_enabled = [] { const char *e = std::getenv("RTK_SHADOW_EARLY_EXIT"); return !(e && e[0] == '0'); }();
-    A.shadow_exit = (exit_enabled && !a->has_refractive && p->collect_stats != 1) ? 1 : 0;
+    A.shadow_exit = (a->knobs.shadow_exit && !a->has_refractive && p->collect_stats != 1) ? 1 : 0;
     RTK_HIP(hipMemsetAsync(a->d_counters, 0, kCounterWords * sizeof(unsigned long long), s));
     if (g.world > 1) {
         // buckets past the end of the frame (padding so that every rank has equal length) stay zero
@@ -547,7 +590,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     bool stream = p->trace_mode == RTK_TRACE_STREAM || (p->trace_mode == RTK_TRACE_AUTO && forks);
     hipEvent_t trial_start = nullptr, trial_end = nullptr;
     if (p->trace_mode == RTK_TRACE_AUTO && forks && !p->collect_stats) {
-        static const bool trials = [] { const char *e = std::getenv("RTK_AUTO_TRIALS"); return !(e && e[0] == '0'); }();
+        const bool trials = a->knobs.auto_trials;
         const uint64_t tsig[3] = {(uint64_t(uint32_t(g.width)) << 32) | uint32_t(g.height), (uint64_t(uint32_t(g.rank)) << 32) | uint32_t(g.world),
                                   (uint64_t(uint32_t(p->spp)) << 32) | (uint64_t(uint32_t(p->max_ray_depth)) << 16) | uint32_t(p->diffuse_rays)};
         if (std::memcmp(tsig, a->trial_sig, sizeof(tsig)) != 0) { std::memcpy(a->trial_sig, tsig, sizeof(tsig)); a->trial_state = 0; }
@@ -588,20 +631,16 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         // Ray-tree nodes per sample: the camera rays plus room for the secondary rays.  Refractive scenes fork (two
         // children per interface), so they get more head room; an overflow is caught on the device and the frame
         // redone by the megakernel.
-        size_t factor = forks ? 8 : 3;
-        if (const char *e = std::getenv("RTK_STREAM_NODE_FACTOR")) { const int v = std::atoi(e); if (v >= 1) factor = size_t(v); }
+        const size_t factor = a->knobs.stream_node_factor > 0 ? size_t(a->knobs.stream_node_factor) : (forks ? 8 : 3);
         rc = ensure_stream_ws(a, out_pixels, n_root * factor + 4096, a->scene.lights.size(), p->spp > 1);
         if (rc != RTK_OK) return rc;
         dev::StreamArgs S;
-        S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root); S.auto_min_lanes = 12;
+        S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root); S.auto_min_lanes = a->knobs.auto_min_lanes;
         // measured on MI355X: the workgroup-cooperative wave walk beats the per-lane walk at every depth, even for the
         // incoherent rays behind refractive surfaces (tools/sweep_stream.sh), so no level switches strategy by default
-        int deep_level = 99, deep_mode = RTK_TRACE_AUTO;
-        if (const char *e = std::getenv("RTK_STREAM_DEEP_LEVEL")) deep_level = std::atoi(e);
-        if (const char *e = std::getenv("RTK_STREAM_DEEP_MODE")) deep_mode = std::atoi(e);
-        if (const char *e = std::getenv("RTK_AUTO_MIN_LANES")) { const int v = std::atoi(e); if (v > 0 && v <= 64) S.auto_min_lanes = uint32_t(v); }
-        int sort_from = forks ? 1 : 99;                        // fork-free trees stay coherent; sorting would only add launches
-        if (const char *e = std::getenv("RTK_STREAM_SORT_FROM")) sort_from = std::atoi(e);
+        const int deep_level = a->knobs.stream_deep_level, deep_mode = a->knobs.stream_deep_mode;
+        // fork-free trees stay coherent; sorting them would only add launches
+        const int sort_from = a->knobs.stream_sort_from >= 0 ? a->knobs.stream_sort_from : (forks ? 1 : 99);
         {
             const DevNode &root = a->tree.dev_nodes[0];
             for (int k = 0; k < 3; ++k) {
@@ -624,7 +663,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         F.only_if = a->ws.ctrl + dev::kCtrlOverflow;
         ef = launch_render(F, RTK_TRACE_GROUP4, p->collect_stats != 0, general, s);
         if (ef != hipSuccess) return hip_fail(ef, "launch fallback k_render");
-        if (std::getenv("RTK_STREAM_DEBUG")) {
+        if (a->knobs.stream_debug) {
             uint32_t h[dev::kCtrlWords];
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h, a->ws.ctrl, sizeof(h), hipMemcpyDeviceToHost);
@@ -639,7 +678,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         // each, against ~3 for a background block).  Started late they are the tail of the frame, so every block reports
         // its cycle count and the next frame of the same shape starts them most-expensive-first.  Only the launch order
         // changes: every block is rendered in full, every frame.  RTK_COST_FEEDBACK=0 turns it off.
-        static const bool feedback = [] { const char *e = std::getenv("RTK_COST_FEEDBACK"); return !(e && e[0] == '0'); }();
+        const bool feedback = a->knobs.cost_feedback;
         const size_t units = size_t(g.buckets_per_rank) * g.blocks_side * g.blocks_side;
         A.n_units = uint32_t(units);
         // RTK_TRACE_AUTO for frames: workgroup-cooperative leaves.  Four waves per pixel block when there are enough blocks
@@ -647,7 +686,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         // there are few (a rank of a sharded frame, a small image: the frame is then as long as its most expensive block,
         // and eight waves get through its big leaves faster).  Measured on config 2 (tools/rank_times.py): 32,400 blocks
         // 0.44 ms (GROUP4) vs 0.87 (GROUP8); 4,050 blocks (one rank of eight) 0.43 vs 0.32.
-        static const size_t group8_below = [] { const char *e = std::getenv("RTK_GROUP8_BELOW_BLOCKS"); return e ? size_t(std::atol(e)) : size_t(9000); }();
+        const size_t group8_below = a->knobs.group8_below;
         const int frame_mode = p->trace_mode != RTK_TRACE_AUTO ? p->trace_mode : (units < group8_below ? RTK_TRACE_GROUP8 : RTK_TRACE_GROUP4);
         if (feedback && units > 0 && units <= 0x7FFFFFFFull) {
             const uint64_t sig[4] = {(uint64_t(uint32_t(g.width)) << 32) | uint32_t(g.height),
@@ -667,10 +706,10 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             if (same_shape) {
                 // The order is refreshed from the newest costs every few frames only: the sort is one small workgroup whose
                 // ~28 us sit in front of the frame, and an order that is a few frames old is as good (costs move slowly).
-                static const unsigned every = [] { const char *e = std::getenv("RTK_COST_RESORT_EVERY"); const int v = e ? std::atoi(e) : 8; return unsigned(v > 0 ? v : 1); }();
+                const unsigned every = a->knobs.resort_every;
                 if (!a->fb_order_valid || a->fb_age >= every) {
                     // blocks that cost less than this many cycles (background, a handful of nodes) are packed four to a workgroup
-                    static const uint32_t light_cycles = [] { const char *e = std::getenv("RTK_LIGHT_BELOW_CYCLES"); return e ? uint32_t(std::atol(e)) : 40000u; }();
+                    const uint32_t light_cycles = a->knobs.light_cycles;
                     const bool group_mode = frame_mode == RTK_TRACE_GROUP4;                 // light packing: GROUP4 only
                     const hipError_t eo = launch_order_by_cost(a->fb_cost, a->fb_bins, a->fb_order, a->fb_order + units, uint32_t(units),
                                                                group_mode ? light_cycles >> 4 : 0u, s);

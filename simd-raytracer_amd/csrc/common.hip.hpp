@@ -89,8 +89,8 @@ __device__ __forceinline__ Ray camera_ray(const RenderArgs &A, const uint32_t px
     float sx = (2.0f * ndc_x) - 1.0f;
     float sy = 1.0f - (2.0f * ndc_y);
     sx *= A.aspect;
-    sx = (float)((double)sx * A.tan_half_fov);                  // render.hpp:55-57 (float *= double)
-    sy = (float)((double)sy * A.tan_half_fov);
+    sx *= A.tan_half_fov;                                       // render.hpp:55-57: float *= tanf(float) (host, api.hip)
+    sy *= A.tan_half_fov;
     const float *M = A.cam_mat;                                 // transpose(camera.matrix) * dir
     V3 d = mk(M[0] * sx + M[3] * sy + M[6] * -1.0f, M[1] * sx + M[4] * sy + M[7] * -1.0f,
               M[2] * sx + M[5] * sy + M[8] * -1.0f);

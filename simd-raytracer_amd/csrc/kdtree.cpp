@@ -106,6 +106,7 @@ void flatten(HostTree &t, int32_t node) {
             t.dev_tris.push_back(d);
             t.dev_tri_ids.push_back(uint32_t(id));
         }
+        t.dev_leaves.push_back(t.dev_nodes[at]);
         return;
     }
     if (hn.child1 >= 0) flatten(t, hn.child1);

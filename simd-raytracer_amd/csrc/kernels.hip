@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
         r = make_ray(mk(0.f, 0.f, 0.f), mk(1.f, 1.f, 1.f));
     }
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {nullptr, 0u, 0u, true, 0u};
+    __shared__ __attribute__((aligned(16))) float wave_bundles[4][kMaxBundles * kBundleFloats];
+    SliceCtx sx = {nullptr, 0u, 0u, true, 0u, wave_bundles[(threadIdx.x >> 6) & 3u]};
     const Cand c = trace<MODE, STATS, LDS_NODES>(A.tree, lds_nodes, r, A.cull != 0, active, st, sx);
     if (active) {
         float4 o0, o1;
@@ -142,7 +143,11 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         group_helper_loop<SLICES>(A.tree, group_sh, slice);
         return;
     }
-    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, light ? 0xFFFFFFFFu : A.slice_min_tris, 0u, true, 0u};
+    // bundles of the current trace (trace.hip.hpp "Bundle culling"): in the group's shared block when helpers must see them,
+    // wave-private otherwise (light workgroups and SLICES == 1 have one owner per wave)
+    __shared__ __attribute__((aligned(16))) float wave_bundles[4][kMaxBundles * kBundleFloats];
+    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, light ? 0xFFFFFFFFu : A.slice_min_tris, 0u, true, 0u,
+                   (SLICES > 1 && !light) ? group_sh->bundles : wave_bundles[wave_in_wg & 3u]};
     const uint32_t lane = threadIdx.x & 63u;
     // one parking area per wave that can own rays: every wave of a light or SLICES == 1 workgroup, one otherwise
     __shared__ float park_lds[4][15][64];                                  // light workgroups exist for SLICES == 4 only (api.hip)
@@ -161,10 +166,6 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
 
 #ifdef RTK_DEBUG_PHASES
     const unsigned long long ph_begin = __builtin_readcyclecounter();
-#endif
-#ifdef RTK_DEBUG_WAVE_TIME
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
-    uint32_t dbg_iters = 0;
 #endif
     const V3 background = mk(A.background[0], A.background[1], A.background[2]);
     const V3 black = mk(0.f, 0.f, 0.f);
@@ -409,15 +410,14 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
             // shadow rays of scenes without transmissive materials only ask "is the closest hit nearer than the light":
             // they may stop at the first hit that says yes (trace(), `exit_t`; A.shadow_exit is set by the host).
             const float exit_t = (A.shadow_exit && pend == PEND_SHADOW) ? shadow_max_t : -1.0f;
-            cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx, kAutoMinLanes, exit_t);
+            // ray class for the bundle culling: shadow rays by light, everything else by depth (camera rays = 0)
+            const uint32_t cls = (pend == PEND_SHADOW) ? 0x100u + (uint32_t)light_k : (uint32_t)depth;
+            cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx, kAutoMinLanes, exit_t, cls);
 #ifdef RTK_DEBUG_PHASES
             sx.c_trace += __builtin_readcyclecounter() - tr0; sx.n_trace += 1u;
             if (ph_after_first == 0) ph_after_first = __builtin_readcyclecounter();
 #endif
         }
-#ifdef RTK_DEBUG_WAVE_TIME
-        dbg_iters += 1;
-#endif
 
         pixel_sum = mk(park[0 * 64], park[1 * 64], park[2 * 64]);
         acc = mk(park[3 * 64], park[4 * 64], park[5 * 64]);
@@ -462,22 +462,15 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         }
     }
 
-#ifdef RTK_DEBUG_WAVE_TIME
-    if (valid && writer) {
-        const unsigned long long dbg_t1 = __builtin_amdgcn_s_memrealtime();
-        float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
-        o[0] = (float)(dbg_t0 & 0xFFFFFFull); o[1] = (float)(dbg_t1 & 0xFFFFFFull); o[2] = (float)dbg_iters;
-    }
-#endif
 #ifdef RTK_DEBUG_PHASES
     if (valid && writer) {
         const unsigned long long ph_now = __builtin_readcyclecounter();
-        const float vals[14] = {(float)(ph_now - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
+        const float vals[17] = {(float)(ph_now - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
                                 (float)sx.n_small, (float)sx.t_small, (float)sx.c_small, (float)sx.n_big, (float)sx.t_big, (float)sx.c_big,
                                 (float)(ph_begin - ph_entry), (float)(ph_first_trace - ph_begin), (float)(ph_after_first - ph_first_trace),
-                                (float)(ph_now - ph_after_first)};
+                                (float)(ph_now - ph_after_first), (float)sx.tally.chunks, (float)sx.tally.surv, (float)sx.tally.tris};
         float v = 0.f;
-        for (int i = 0; i < 14; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
+        for (int i = 0; i < 17; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
         float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
         o[0] = v; o[1] = 0.f; o[2] = 0.f;
     }
@@ -505,7 +498,7 @@ __global__ __launch_bounds__(64 * SLICES, 8) void k_primary(RenderArgs A) {
     GroupShared *const group_sh = group_st.get();
     const uint32_t slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((threadIdx.x >> 6) + blockIdx.x) % (uint32_t)SLICES));
     if (slice != 0u) { group_helper_loop<SLICES>(A.tree, group_sh, slice); return; }
-    SliceCtx sx = {group_sh, A.slice_min_tris, 0u, true, 0u};
+    SliceCtx sx = {group_sh, A.slice_min_tris, 0u, true, 0u, group_sh->bundles};
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gwave = blockIdx.x;

@@ -43,7 +43,7 @@ struct RenderArgs {
     float background[3];
     uint32_t width, height;
     float aspect;
-    double tan_half_fov;
+    float tan_half_fov;               // tanf(float(radians) / 2.0f), render.hpp:55-57
     int spp, max_depth, diffuse_rays;
     uint32_t seed;
     float shadow_bias, reflection_bias, refraction_bias;

@@ -124,6 +124,7 @@ struct HostTree {
     std::vector<int32_t> leaf_refs;            // unpadded leaf triangle lists, reference leaf order
     // device-order flattening
     std::vector<DevNode> dev_nodes;
+    std::vector<DevNode> dev_leaves;           // the leaves of dev_nodes alone, same order (leaf-list traversal, trace.hip.hpp)
     std::vector<DevTri> dev_tris;
     std::vector<uint32_t> dev_tri_ids;         // leaf-ref -> global triangle index
     std::vector<DevShade> dev_shade;           // per global triangle

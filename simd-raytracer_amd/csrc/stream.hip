@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     for (uint32_t j = 0; j < level; ++j) hit_base += ctrl[kCtrlHitCount + j];
     const uint32_t n_items = (count + 63u) >> 6;
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u};
+    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u, SLICES > 1 ? group_sh->bundles : nullptr};
     uint32_t nrays = 0;
 
     for (uint32_t item = gunit; item < n_items; item = LEVEL0 ? n_items : next_item(ctrl + kCtrlTicket + level, n_units_grid)) {
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     const uint32_t n_items = ((n_hits + 63u) >> 6) * n_lights;
     const float PI_F = 3.14159265358979323846f;
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u};
+    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u, SLICES > 1 ? group_sh->bundles : nullptr};
     uint32_t nrays = 0;
 
     for (uint32_t item = gunit; item < n_items; item = next_item(ctrl + kCtrlTicket + kLevels + S.level, n_units_grid)) {

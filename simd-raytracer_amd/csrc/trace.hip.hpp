@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "rtk_internal.hpp"
 
 namespace rtk {
@@ -55,12 +57,12 @@ struct TreeView {
     const DevTri *tris;
     const uint32_t *tri_ids;
     const DevShade *shade;
+    const DevNode *leaves;       // the leaves of `nodes` alone, in traversal order (a = first leaf ref, b = count)
+    uint32_t n_leaves;
     uint32_t n_nodes;
     float eps;
     int normalize;
-#ifdef RTK_DEBUG_KHIST
-    unsigned long long *khist;   // diagnostic: leaf visits by number of participating rays (see tools/khist.py)
-#endif
+    int bundle_cull;             // 1: leaves may be pre-culled against the wave's ray bundle (all vertex coordinates are small enough)
 };
 
 // Wave-uniform loads: address space 4 (constant) forces s_load_* through the scalar cache, so one
@@ -263,91 +265,253 @@ __device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t fi
     }
 }
 
-// ---- Vector-broadcast variant (experimental, -DRTK_VEC_TREE; measured slower than the scalar-load variant) -------------
-// Scalar loads complete out of order, so a wave can only wait for ALL of them (lgkmcnt(0)): the prefetch can never be
-// more than one triangle deep, and the 225 KB of leaf references stream through a 16 KB scalar cache, so most fetches
-// pay an L2 round trip (measured in situ: ~550 cycles per triangle step, 950 per node step, against ~150 cycles of
-// arithmetic).  Vector loads with the same address in every lane (one request, broadcast by the TA) return IN order:
-// vmcnt lets triangle k be consumed while k+1 and k+2 are in flight.  The loop is unrolled by three so that the three
-// register sets rotate without moves.  `vz` is a per-lane zero the compiler cannot see through; without it the loads
-// would be turned back into scalar loads.
-typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ uint32_t opaque_lane_zero() {
-    uint32_t z;
-    asm("v_mov_b32 %0, 0" : "=v"(z));
-    return z;
+// ------------------------------------------------------------------------------------------------
+// Bundle culling.  The rays a wave traces together come in a few coherent classes (the camera rays of an 8x8 pixel block,
+// the shadow rays of a surface patch towards one light, the reflections off a plane): of the hundreds of triangles in a
+// leaf only a handful can be hit by ANY ray of a class.  So a leaf is first tested 64 triangles at a time, ONE TRIANGLE
+// PER LANE, against each class's BUNDLE as a whole: the arithmetic of triangle_packet::intersect (kd_tree_simd.hpp:25-60)
+// is evaluated in interval arithmetic over the box of the bundle's origins and directions, and a triangle is dropped when
+// one of the tests of :33-57 fails for the whole interval.  Only the survivors go through the exact per-ray test
+// (tri_step), in leaf order, their data broadcast from the lane that holds them (v_readlane, no memory access).
+//
+// Exactness.  The interval evaluation follows tri_step's expression tree operation by operation.  IEEE rounding is
+// monotone, so for every float operation z = fl(x op y) of tri_step with x in [xl, xh], y in [yl, yh], z lies between the
+// smallest and the largest of the op's values at the interval corners, computed in the same float arithmetic.  By induction
+// every float the exact test computes for any ray of the bundle lies inside the interval computed here -- no error analysis,
+// no epsilon.  (1/det is bounded through v_rcp_f32, |error| <= 1 ulp, widened by 8 ulp.)  A dropped triangle would have
+// failed the exact test for every ray, so it could never have updated a candidate: results are bit-identical.
+// Requirements, checked once per bundle / per accel: all operands finite and below 1e9 in magnitude, so that no
+// intermediate overflows (inf - inf and 0 * inf would produce NaNs that v_min/v_max silently drop).
+//
+// A trace's bundles (at most kMaxBundles, one per ray class the caller names; further classes are merged into the last)
+// live in LDS, kBundleFloats floats each: [0..11] the boxes below, [12..17] bounds of fl(1/d) per axis (lx,hx,ly,hy,lz,hz),
+// [18] flags.  They are read back with the same address in every lane: the values then sit in VGPRs only while a culling
+// pass needs them (neither the SGPR nor the VGPR budget of the render kernels has room for them across a trace).
+struct Bundle {
+    float olx, oly, olz, ohx, ohy, ohz;   // box of the ray origins
+    float dlx, dly, dlz, dhx, dhy, dhz;   // box of the ray directions
+    uint32_t flags;
+};
+enum : uint32_t { BUNDLE_OK = 1u, BUNDLE_ALL_CULL = 2u, BUNDLE_INVX = 4u, BUNDLE_INVY = 8u, BUNDLE_INVZ = 16u };
+constexpr float kBundleLimit = 1.0e9f;   // |coordinate| bound under which the interval arithmetic cannot overflow
+constexpr uint32_t kBundleMinTris = 4;   // leaves (or slices) smaller than this are tested triangle by triangle
+constexpr int kMaxBundles = 3;
+constexpr int kBundleFloats = 20;
+
+struct BundleSet {       // wave-uniform handle of the current trace's bundles
+    const float *lds;    // [kMaxBundles][kBundleFloats]
+    uint32_t n;          // 0: no culling for this trace
+};
+
+// Wave-wide min / max through DPP (quad_perm, row_shr within rows of 16, then row_bcast across rows; the classic gfx9
+// reduction): the full result ends up in lane 63.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(const float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
-__device__ __forceinline__ TriS load_tri_bcast(const float *tp, const uint32_t vz) {
-    const char *q = reinterpret_cast<const char *>(tp) + vz;
-    const f32x4_a4 a = *reinterpret_cast<const f32x4_a4 *>(q);
-    const f32x4_a4 b = *reinterpret_cast<const f32x4_a4 *>(q + 16);
-    TriS t;
-    t.v0x = a.x; t.v0y = a.y; t.v0z = a.z; t.e1x = a.w;
-    t.e1y = b.x; t.e1z = b.y; t.e2x = b.z; t.e2y = b.w;
-    t.e2z = *reinterpret_cast<const float *>(q + 32);
-    return t;
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax(float v) {
+#define RTK_RED_STEP(CTRL, ROWS) { const float o = dpp_move<CTRL, ROWS>(v); v = MAX ? __builtin_fmaxf(v, o) : __builtin_fminf(v, o); }
+    RTK_RED_STEP(0xB1, 0xF)     // quad_perm [1,0,3,2]
+    RTK_RED_STEP(0x4E, 0xF)     // quad_perm [2,3,0,1]
+    RTK_RED_STEP(0x114, 0xF)    // row_shr:4
+    RTK_RED_STEP(0x118, 0xF)    // row_shr:8   -> lane 15 of every row holds the row's result
+    RTK_RED_STEP(0x142, 0xA)    // row_bcast:15 -> lanes 31 and 63 hold two rows
+    RTK_RED_STEP(0x143, 0xC)    // row_bcast:31 -> lane 63 holds all four
+#undef RTK_RED_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// One triangle against the wave's rays: the arithmetic of test_triangle with wave-level early outs between the stages
-// (the per-lane predicate is a 64-bit mask in SGPRs, see leaf_range_wave).
-__device__ __forceinline__ void tri_step_wave(const TriS &cur, const uint32_t k, const Ray &r, const bool cull, const float eps,
-                                              const unsigned long long pass_mask, const uint32_t lane, Cand &best) {
-    const float pvx = r.d.y * cur.e2z - r.d.z * cur.e2y;
-    const float pvy = r.d.z * cur.e2x - r.d.x * cur.e2z;
-    const float pvz = r.d.x * cur.e2y - r.d.y * cur.e2x;
-    const float det = cur.e1x * pvx + cur.e1y * pvy + cur.e1z * pvz;
-    unsigned long long m = pass_mask & __builtin_amdgcn_ballot_w64(eps <= (cull ? det : __builtin_fabsf(det)));
-    if (m == 0ull) return;
-    const float inv_det = (1.0f / det);
-    const float tvx = r.o.x - cur.v0x, tvy = r.o.y - cur.v0y, tvz = r.o.z - cur.v0z;
-    const float u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv_det;
-    m &= __builtin_amdgcn_ballot_w64(0.0f <= u) & __builtin_amdgcn_ballot_w64(u <= 1.0f);
-    if (m == 0ull) return;
-    const float qx = tvy * cur.e1z - tvz * cur.e1y;
-    const float qy = tvz * cur.e1x - tvx * cur.e1z;
-    const float qz = tvx * cur.e1y - tvy * cur.e1x;
-    const float v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv_det;
-    m &= __builtin_amdgcn_ballot_w64(0.0f <= v) & __builtin_amdgcn_ballot_w64(u + v <= 1.0f);
-    if (m == 0ull) return;
-    const float t = (cur.e2x * qx + cur.e2y * qy + cur.e2z * qz) * inv_det;
-    m &= __builtin_amdgcn_ballot_w64(eps < t) & __builtin_amdgcn_ballot_w64(t < best.t);
-    if (m == 0ull) return;
-    if ((m >> lane) & 1ull) { best.t = t; best.u = u; best.v = v; best.k = k; }
+// bounds of the rays of the lanes with `in`
+__device__ __forceinline__ Bundle make_bundle(const Ray &r, const bool cull, const bool in) {
+    const float inf = __builtin_inff();
+    Bundle B;
+    B.olx = wave_minmax<false>(in ? r.o.x : inf);  B.ohx = wave_minmax<true>(in ? r.o.x : -inf);
+    B.oly = wave_minmax<false>(in ? r.o.y : inf);  B.ohy = wave_minmax<true>(in ? r.o.y : -inf);
+    B.olz = wave_minmax<false>(in ? r.o.z : inf);  B.ohz = wave_minmax<true>(in ? r.o.z : -inf);
+    B.dlx = wave_minmax<false>(in ? r.d.x : inf);  B.dhx = wave_minmax<true>(in ? r.d.x : -inf);
+    B.dly = wave_minmax<false>(in ? r.d.y : inf);  B.dhy = wave_minmax<true>(in ? r.d.y : -inf);
+    B.dlz = wave_minmax<false>(in ? r.d.z : inf);  B.dhz = wave_minmax<true>(in ? r.d.z : -inf);
+    // a NaN component is invisible to min/max: any ray that is not finite and small switches the culling off
+    const float L = kBundleLimit;
+    const bool lane_ok = (__builtin_fabsf(r.o.x) <= L) & (__builtin_fabsf(r.o.y) <= L) & (__builtin_fabsf(r.o.z) <= L) &
+                         (__builtin_fabsf(r.d.x) <= L) & (__builtin_fabsf(r.d.y) <= L) & (__builtin_fabsf(r.d.z) <= L);
+    const bool ok = __builtin_amdgcn_ballot_w64(in & !lane_ok) == 0ull;
+    B.flags = (ok ? BUNDLE_OK : 0u) | ((__builtin_amdgcn_ballot_w64(in & !cull) == 0ull) ? BUNDLE_ALL_CULL : 0u);
+    return B;
 }
 
-__device__ __forceinline__ void leaf_range_bcast(const float *tris, const uint32_t vz, const uint32_t first, const uint32_t lo,
-                                                 const uint32_t hi, const Ray &r, const bool cull, const float eps,
-                                                 const bool pass, Cand &best) {
-    if (lo >= hi) return;
+// Splits the active lanes by `cls` into at most kMaxBundles bundles (classes beyond that join the last one), writes them to
+// `lds` and tells every lane which bundle its ray belongs to.  Returns the number of bundles, 0 when culling is off for this trace.
+__device__ __forceinline__ uint32_t make_bundles(const Ray &r, const bool cull, const bool active, const uint32_t cls, float *lds,
+                                                 uint32_t &cidx) {
+    const uint32_t lane = __lane_id();
+    unsigned long long rem = __builtin_amdgcn_ballot_w64(active);
+    uint32_t n = 0u;
+    cidx = 0u;
+    while (rem != 0ull) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __builtin_ctzll(rem));
+        const bool mine = ((rem >> lane) & 1ull) != 0ull;
+        const bool in = mine & ((n == (uint32_t)(kMaxBundles - 1)) | (cls == c));
+        const Bundle B = make_bundle(r, cull, in);
+        if ((B.flags & BUNDLE_OK) == 0u) return 0u;
+        // fl(1/d) per axis: 1/d is monotone decreasing on either side of zero, and so is its rounding; directions with a
+        // tiny or zero component anywhere in the bundle give no bound on that axis (and could overflow the products)
+        uint32_t flags = B.flags;
+        if ((1.0e-30f < B.dlx) | (B.dhx < -1.0e-30f)) flags |= BUNDLE_INVX;
+        if ((1.0e-30f < B.dly) | (B.dhy < -1.0e-30f)) flags |= BUNDLE_INVY;
+        if ((1.0e-30f < B.dlz) | (B.dhz < -1.0e-30f)) flags |= BUNDLE_INVZ;
+        if (lane == 0u) {
+            float4 *q = reinterpret_cast<float4 *>(lds + n * (uint32_t)kBundleFloats);
+            q[0] = make_float4(B.olx, B.oly, B.olz, B.ohx);
+            q[1] = make_float4(B.ohy, B.ohz, B.dlx, B.dly);
+            q[2] = make_float4(B.dlz, B.dhx, B.dhy, B.dhz);
+            q[3] = make_float4(1.0f / B.dhx, 1.0f / B.dlx, 1.0f / B.dhy, 1.0f / B.dly);
+            q[4] = make_float4(1.0f / B.dhz, 1.0f / B.dlz, __uint_as_float(flags), 0.0f);
+        }
+        if (in) cidx = n;
+        rem &= ~__builtin_amdgcn_ballot_w64(in);
+        n += 1u;
+    }
+    return n;
+}
+
+struct BundleRegs {      // one bundle read back from LDS (same address in every lane)
+    Bundle b;
+    float ilx, ihx, ily, ihy, ilz, ihz;
+};
+__device__ __forceinline__ BundleRegs load_bundle(const float *lds, const uint32_t k) {
+    const float4 *q = reinterpret_cast<const float4 *>(lds + k * (uint32_t)kBundleFloats);
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    BundleRegs R;
+    R.b.olx = a.x; R.b.oly = a.y; R.b.olz = a.z; R.b.ohx = a.w;
+    R.b.ohy = b.x; R.b.ohz = b.y; R.b.dlx = b.z; R.b.dly = b.w;
+    R.b.dlz = c.x; R.b.dhx = c.y; R.b.dhy = c.z; R.b.dhz = c.w;
+    R.ilx = d.x; R.ihx = d.y; R.ily = d.z; R.ihy = d.w;
+    R.ilz = e.x; R.ihz = e.y;
+    R.b.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e.z));
+    return R;
+}
+
+struct Iv { float lo, hi; };
+__device__ __forceinline__ Iv iv_add(const Iv a, const Iv b) { return Iv{a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ Iv iv_sub(const Iv a, const Iv b) { return Iv{a.lo - b.hi, a.hi - b.lo}; }
+__device__ __forceinline__ Iv iv_scale(const Iv a, const float s) {           // interval * number
+    const float p = a.lo * s, q = a.hi * s;
+    return Iv{__builtin_fminf(p, q), __builtin_fmaxf(p, q)};
+}
+__device__ __forceinline__ Iv iv_mul(const Iv a, const Iv b) {                 // interval * interval
+    const float p = a.lo * b.lo, q = a.lo * b.hi, r = a.hi * b.lo, s = a.hi * b.hi;
+    return Iv{__builtin_fminf(__builtin_fminf(p, q), __builtin_fminf(r, s)), __builtin_fmaxf(__builtin_fmaxf(p, q), __builtin_fmaxf(r, s))};
+}
+
+// true: no ray of the bundle can pass triangle_packet::intersect for this lane's triangle (see "Bundle culling")
+__device__ __forceinline__ bool bundle_misses(const Bundle &B, const float eps, const float v0x, const float v0y, const float v0z,
+                                              const float e1x, const float e1y, const float e1z, const float e2x,
+                                              const float e2y, const float e2z) {
+    const Iv dx = {B.dlx, B.dhx}, dy = {B.dly, B.dhy}, dz = {B.dlz, B.dhz};
+    // pvec = d x e2, det = e1 . pvec                                             (tri_step: pvx, pvy, pvz, det)
+    const Iv pvx = iv_sub(iv_scale(dy, e2z), iv_scale(dz, e2y));
+    const Iv pvy = iv_sub(iv_scale(dz, e2x), iv_scale(dx, e2z));
+    const Iv pvz = iv_sub(iv_scale(dx, e2y), iv_scale(dy, e2x));
+    const Iv det = iv_add(iv_add(iv_scale(pvx, e1x), iv_scale(pvy, e1y)), iv_scale(pvz, e1z));
+    const bool all_cull = (B.flags & BUNDLE_ALL_CULL) != 0u;
+    // eps <= det (culling rays) / eps <= |det| (the others), kd_tree_simd.hpp:33-38.  Comparisons are written so that a
+    // NaN bound keeps the triangle.
+    const bool none = (det.hi < eps) & (all_cull | (-eps < det.lo));              // no ray passes the determinant test
+    const bool pos = !(det.hi < eps);                                             // some ray may have det >= eps
+    const bool neg = !all_cull & !(-eps < det.lo);                                // some non-culling ray may have det <= -eps
+    // tvec = o - v0, un = tvec . pvec, qvec = tvec x e1, vn = d . qvec, tn = e2 . qvec
+    const Iv tvx = {B.olx - v0x, B.ohx - v0x}, tvy = {B.oly - v0y, B.ohy - v0y}, tvz = {B.olz - v0z, B.ohz - v0z};
+    Iv un = iv_add(iv_add(iv_mul(tvx, pvx), iv_mul(tvy, pvy)), iv_mul(tvz, pvz));
+    const Iv qx = iv_sub(iv_scale(tvy, e1z), iv_scale(tvz, e1y));
+    const Iv qy = iv_sub(iv_scale(tvz, e1x), iv_scale(tvx, e1z));
+    const Iv qz = iv_sub(iv_scale(tvx, e1y), iv_scale(tvy, e1x));
+    Iv vn = iv_add(iv_add(iv_mul(dx, qx), iv_mul(dy, qy)), iv_mul(dz, qz));
+    Iv tn = iv_add(iv_add(iv_scale(qx, e2x), iv_scale(qy, e2y)), iv_scale(qz, e2z));
+    // one sign of det is left: normalise to det > 0 (x * inv_det == (-x) * (-inv_det) exactly, and fl(1/-d) == -fl(1/d))
+    float dl = det.lo, dh = det.hi;
+    if (neg) {
+        dl = -det.hi; dh = -det.lo;
+        un = Iv{-un.hi, -un.lo}; vn = Iv{-vn.hi, -vn.lo}; tn = Iv{-tn.hi, -tn.lo};
+    }
+    dl = __builtin_fmaxf(dl, eps);                                                // rays with a smaller determinant fail the test above
+    // fl(1/det) for det in [dl, dh]: v_rcp_f32 is within 1 ulp of 1/x, fl(1/x) within 1/2; 8 ulp of slack
+    const float il = __builtin_amdgcn_rcpf(dh) * 0.999999f, ih = __builtin_amdgcn_rcpf(dl) * 1.000001f;
+    const float u_hi = __builtin_fmaxf(un.hi * il, un.hi * ih), u_lo = __builtin_fminf(un.lo * il, un.lo * ih);
+    const float v_hi = __builtin_fmaxf(vn.hi * il, vn.hi * ih), v_lo = __builtin_fminf(vn.lo * il, vn.lo * ih);
+    const float t_hi = __builtin_fmaxf(tn.hi * il, tn.hi * ih);
+    // 0 <= u <= 1, 0 <= v, u + v <= 1, eps < t                                     (kd_tree_simd.hpp:47, :54, :57)
+    const bool out = (u_hi < 0.0f) | (1.0f < u_lo) | (v_hi < 0.0f) | (1.0f < u_lo + v_lo) | (t_hi <= eps);
+    // both signs possible: the bundle straddles the triangle's plane, keep; huge determinants: no bound on 1/det, keep
+    return none | (out & !(pos & neg) & (dh < 1.0e30f));
+}
+
+// Leaf references [lo, hi) of the leaf starting at `first`, bundle-culled 64 at a time (one triangle per lane), the
+// survivors tested exactly in leaf order.  `cidx` = the bundle of this lane's ray.
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+#ifdef RTK_DEBUG_PHASES
+struct CullTally { uint32_t chunks, surv, tris; };
+#define RTK_TALLY_ARG , CullTally &tally
+#define RTK_TALLY_PASS , tally
+#else
+#define RTK_TALLY_ARG
+#define RTK_TALLY_PASS
+#endif
+__device__ __forceinline__ void leaf_range_bundle(const float *tris, const uint32_t first, const uint32_t lo, const uint32_t hi,
+                                                  const Ray &r, const bool cull, const float eps, const bool pass,
+                                                  const uint32_t cidx, const BundleSet &BS, Cand &best RTK_TALLY_ARG) {
     const unsigned long long pass_mask = __builtin_amdgcn_ballot_w64(pass);
     const uint32_t lane = __lane_id();
-    const float *base = tris + (size_t)first * 9;
-    const uint32_t last = hi - 1u;                                         // prefetches past the range re-read its last triangle
-    uint32_t k = lo;
-    TriS A = load_tri_bcast(base + (size_t)k * 9, vz);
-    TriS B = load_tri_bcast(base + (size_t)(k + 1u < hi ? k + 1u : last) * 9, vz);
-    TriS C = load_tri_bcast(base + (size_t)(k + 2u < hi ? k + 2u : last) * 9, vz);
-    for (;;) {
-        tri_step_wave(A, first + k, r, cull, eps, pass_mask, lane, best);
-        if (k + 1u >= hi) break;
-        A = load_tri_bcast(base + (size_t)(k + 3u < hi ? k + 3u : last) * 9, vz);
-        tri_step_wave(B, first + k + 1u, r, cull, eps, pass_mask, lane, best);
-        if (k + 2u >= hi) break;
-        B = load_tri_bcast(base + (size_t)(k + 4u < hi ? k + 4u : last) * 9, vz);
-        tri_step_wave(C, first + k + 2u, r, cull, eps, pass_mask, lane, best);
-        if (k + 3u >= hi) break;
-        C = load_tri_bcast(base + (size_t)(k + 5u < hi ? k + 5u : last) * 9, vz);
-        k += 3u;
+    // which bundles have a ray in this leaf at all
+    unsigned long long in_k[kMaxBundles];
+#pragma unroll
+    for (int k = 0; k < kMaxBundles; ++k) in_k[k] = __builtin_amdgcn_ballot_w64(pass & (cidx == (uint32_t)k));
+    for (uint32_t base = lo; base < hi; base += 64u) {
+        const uint32_t cnt = hi - base < 64u ? hi - base : 64u;
+        const bool have = lane < cnt;
+        const F3 *tp = reinterpret_cast<const F3 *>(tris + (size_t)(first + base + (have ? lane : 0u)) * 9);
+        const F3 v0 = tp[0], e1 = tp[1], e2 = tp[2];
+        bool keep = false;
+#pragma unroll
+        for (int k = 0; k < kMaxBundles; ++k) {
+            if ((uint32_t)k < BS.n && in_k[k] != 0ull) {
+                const BundleRegs R = load_bundle(BS.lds, (uint32_t)k);
+                keep = keep | !bundle_misses(R.b, eps, v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z);
+            }
+        }
+        unsigned long long surv = __builtin_amdgcn_ballot_w64(have & keep);
+#ifdef RTK_DEBUG_PHASES
+        tally.chunks += 1u; tally.surv += (uint32_t)__popcll(surv); tally.tris += cnt;
+#endif
+        while (surv != 0ull) {
+            const int j = __builtin_ctzll(surv);
+            surv &= surv - 1ull;
+            TriS cur;
+            cur.v0x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0.x), j));
+            cur.v0y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0.y), j));
+            cur.v0z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0.z), j));
+            cur.e1x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1.x), j));
+            cur.e1y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1.y), j));
+            cur.e1z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e1.z), j));
+            cur.e2x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e2.x), j));
+            cur.e2y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e2.y), j));
+            cur.e2z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e2.z), j));
+            tri_step(cur, first + base + (uint32_t)j, r, cull, eps, pass_mask, lane, best);
+        }
     }
 }
 
-#ifndef RTK_VEC_TREE
-#define RTK_LEAF_RANGE(T_, tris_, first_, lo_, hi_, r_, cull_, pass_, best_) \
-    leaf_range_wave((cptr_f32)(const void *)(T_).tris, first_, lo_, hi_, r_, cull_, (T_).eps, pass_, best_)
-#else
-#define RTK_LEAF_RANGE(T_, tris_, first_, lo_, hi_, r_, cull_, pass_, best_) \
-    leaf_range_bcast(reinterpret_cast<const float *>((T_).tris), vz, first_, lo_, hi_, r_, cull_, (T_).eps, pass_, best_)
-#endif
+// leaf references [lo, hi): bundle-culled when the trace has bundles and the range is worth a 64-wide pass
+__device__ __forceinline__ void leaf_range(const TreeView &T, const uint32_t first, const uint32_t lo, const uint32_t hi,
+                                           const Ray &r, const bool cull, const bool pass, const uint32_t cidx,
+                                           const BundleSet &BS, Cand &best RTK_TALLY_ARG) {
+    if (lo >= hi) return;
+    if (BS.n != 0u && hi - lo >= kBundleMinTris)
+        leaf_range_bundle(reinterpret_cast<const float *>(T.tris), first, lo, hi, r, cull, T.eps, pass, cidx, BS, best RTK_TALLY_PASS);
+    else
+        leaf_range_wave((cptr_f32)(const void *)T.tris, first, lo, hi, r, cull, T.eps, pass, best);
+}
 
 // Workgroup-cooperative leaves (SLICES > 1).  A workgroup of SLICES waves serves ONE 8x8 pixel block: wave 0 (the
 // owner) holds the 64 rays, runs the shading state machine and walks the tree; waves 1..SLICES-1 are helpers that
@@ -357,16 +521,19 @@ __device__ __forceinline__ void leaf_range_bcast(const float *tris, const uint32
 // triangle with the smallest t" rule.  This divides the longest dependency chain of a frame (one wave grinding
 // through a 500-triangle leaf) by SLICES without replicating traversal or shading work.
 struct GroupShared {
-    float4 ray_o[64];            // origin xyz (w unused); rewritten only when the owner starts a new ray
+    float4 ray_o[64];            // origin xyz, w = the lane's bundle index; rewritten only when the owner starts a new ray
     float4 ray_d[64];            // direction xyz
     float best_t[64];            // per-lane best t before the leaf
     unsigned long long pass_mask, cull_mask;
     uint32_t first, count;       // leaf references [first, first+count)
     uint32_t kind;               // 0 = leaf, 1 = exit
     uint32_t ray_gen;            // bumped whenever ray_o/ray_d change
-    uint32_t pad[2];
+    uint32_t n_bundles;          // bundles of the rays in ray_o/ray_d (0 = no culling)
+    uint32_t pad[3];
+    float bundles[kMaxBundles * kBundleFloats];    // written by make_bundles at the start of the owner's trace
     float4 result[][64];         // [SLICES][64] winners of slices 1..SLICES-1: t,u,v,k (storage: GroupStorage<SLICES>)
 };
+static_assert(offsetof(GroupShared, bundles) % 16 == 0, "bundle images are read with 16-byte LDS loads");
 template <int SLICES>
 struct alignas(16) GroupStorage {
     unsigned char raw[sizeof(GroupShared) + (size_t)SLICES * 64 * sizeof(float4)];
@@ -380,22 +547,33 @@ struct SliceCtx {
     uint32_t ray_gen;    // owner: generation of the rays currently in LDS
     bool rays_dirty;     // owner: the current ray is not in LDS yet
     uint32_t work;       // wave-uniform tally of nodes stepped + triangles iterated (a cost estimate for scheduling)
+    float *bundle_lds;   // [kMaxBundles * kBundleFloats] floats of LDS for this trace's bundles: sh->bundles when SLICES > 1,
+                         // a wave-private area otherwise; nullptr = no bundle culling / leaf-list traversal
 #ifdef RTK_DEBUG_PHASES
     // diagnostic (tools/phase_times.py): cycles and counts of the owner's walk by phase
     unsigned long long c_small = 0, c_big = 0, c_trace = 0;
     uint32_t n_steps = 0, n_small = 0, n_big = 0, t_small = 0, t_big = 0, n_trace = 0;
+    CullTally tally = {0u, 0u, 0u};   // owner's own chunks / survivors / triangles seen by the bundle culling
 #endif
 };
+#ifdef RTK_DEBUG_PHASES
+#define RTK_SX_TALLY , sx.tally
+#else
+#define RTK_SX_TALLY
+#endif
 
 // helper waves: serve leaf slices until the owner posts GROUP_EXIT
 template <int SLICES>
 __device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared *sh, const uint32_t slice) {
-    const uint32_t vz = opaque_lane_zero();
-    (void)vz;
     const uint32_t lane = __lane_id();
     uint32_t my_gen = 0xFFFFFFFFu;
     Ray r;
     r.o = mk(0.f, 0.f, 0.f); r.d = mk(0.f, 0.f, 0.f); r.inv = mk(0.f, 0.f, 0.f);
+    uint32_t cidx = 0u;
+    BundleSet BS = {sh->bundles, 0u};
+#ifdef RTK_DEBUG_PHASES
+    CullTally tally = {0u, 0u, 0u};
+#endif
     for (;;) {
         __syncthreads();                                                   // B1: a command is posted
         const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->kind);
@@ -404,6 +582,8 @@ __device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared
         if (gen != my_gen) {
             const float4 o = sh->ray_o[lane], d = sh->ray_d[lane];
             r.o = mk(o.x, o.y, o.z); r.d = mk(d.x, d.y, d.z);
+            cidx = __float_as_uint(o.w);
+            BS.n = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->n_bundles);
             my_gen = gen;
         }
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->first);
@@ -412,7 +592,7 @@ __device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared
         Cand mine;
         mine.t = sh->best_t[lane]; mine.u = 0.f; mine.v = 0.f; mine.k = kMiss;
         const uint32_t lo = (count * slice) / (uint32_t)SLICES, hi = (count * (slice + 1u)) / (uint32_t)SLICES;
-        RTK_LEAF_RANGE(T, tris, first, lo, hi, r, ((cm >> lane) & 1ull) != 0ull, ((pm >> lane) & 1ull) != 0ull, mine);
+        leaf_range(T, first, lo, hi, r, ((cm >> lane) & 1ull) != 0ull, ((pm >> lane) & 1ull) != 0ull, cidx, BS, mine RTK_TALLY_PASS);
         sh->result[slice][lane] = make_float4(mine.t, mine.u, mine.v, __uint_as_float(mine.k));
         __syncthreads();                                                   // B2: results are in LDS
     }
@@ -423,29 +603,149 @@ __device__ __forceinline__ void group_post_exit(GroupShared *sh) {
     __syncthreads();
 }
 
+// One leaf for the lanes with `pass`: tested by this wave alone, or (SLICES > 1, leaf of at least sx.min_tris triangles) cut
+// into SLICES contiguous ranges, one per wave of the workgroup, and merged in range order with a strict '<'.
+template <int SLICES>
+__device__ __forceinline__ void process_leaf(const TreeView &T, const uint32_t a, const uint32_t b, const Ray &r, const bool cull,
+                                             const bool pass, const uint32_t cidx, const BundleSet &BS, Cand &best, SliceCtx &sx) {
+    if (SLICES > 1 && b >= sx.min_tris) {
+        GroupShared *sh = sx.sh;
+        const uint32_t lane = __lane_id();
+        if (sx.rays_dirty) {
+            sh->ray_o[lane] = make_float4(r.o.x, r.o.y, r.o.z, __uint_as_float(cidx));
+            sh->ray_d[lane] = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
+            if (lane == 0u) sh->n_bundles = BS.n;                          // the bundles themselves are in sh->bundles already
+            sx.ray_gen += 1u;
+            sx.rays_dirty = false;
+        }
+        sh->best_t[lane] = best.t;
+        const unsigned long long pm = __builtin_amdgcn_ballot_w64(pass), cm = __builtin_amdgcn_ballot_w64(cull);
+        if (lane == 0u) {
+            sh->pass_mask = pm; sh->cull_mask = cm;
+            sh->first = a; sh->count = b; sh->kind = GROUP_LEAF; sh->ray_gen = sx.ray_gen;
+        }
+        __syncthreads();                                       // B1: helpers start on their slices
+        leaf_range(T, a, 0u, b / (uint32_t)SLICES, r, cull, pass, cidx, BS, best RTK_SX_TALLY);
+        __syncthreads();                                       // B2: helper results are in LDS
+#pragma unroll
+        for (int s = 1; s < SLICES; ++s) {
+            const float4 c = sh->result[s][lane];
+            if (c.x < best.t) { best.t = c.x; best.u = c.y; best.v = c.z; best.k = __float_as_uint(c.w); }
+        }
+    } else {
+        leaf_range(T, a, 0u, b, r, cull, pass, cidx, BS, best RTK_SX_TALLY);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Leaf-list traversal.  A lane visits a leaf iff the leaf's own box test passes (`box hit && !(best_t < t_min)`,
+// kd_tree_simd.hpp:200-205) at the moment the walk reaches it: the tests of its ancestors are IMPLIED.  A child box is
+// a subset of its parent's (aabb3::split, aabb3.hpp:43-60: one plane moved to the midpoint), the slab test is built from
+// monotone float operations (subtract, multiply by the same 1/d, compare-select), so per axis the child's [t1, t2] lies inside
+// the parent's, t_min(child) >= t_min(parent), and a hit child means a hit parent; the candidate's t only shrinks, so
+// `best_t >= t_min(child)` now implies `best_t_then >= t_min(parent)` earlier.  (A NaN from 0 * inf only ever drops a constraint
+// of the node it occurs in; the parent's constraint on that axis is then no stronger.)  Leaves are visited in traversal order,
+// so every lane sees exactly the leaf sequence of the stack walk -- without the inner nodes.
+// The list is first cut down, 64 leaves at a time (one leaf per lane), to the leaves a BUNDLE can touch at all (interval
+// slab test, same monotonicity argument as the triangle culling); each survivor then costs one exact 64-ray box test.
+__device__ __forceinline__ bool bundle_may_hit_box(const BundleRegs &R, const float lo0, const float lo1, const float lo2,
+                                                   const float hi0, const float hi1, const float hi2) {
+    const Bundle &B = R.b;
+    float t_min_lo = 0.0f, t_max_hi = kFltMax;
+    bool miss = false;
+    if ((B.flags & BUNDLE_INVX) != 0u) {
+        const Iv inv = {R.ilx, R.ihx};
+        const Iv a = iv_mul(Iv{lo0 - B.ohx, lo0 - B.olx}, inv), c = iv_mul(Iv{hi0 - B.ohx, hi0 - B.olx}, inv);
+        t_min_lo = __builtin_fmaxf(t_min_lo, __builtin_fminf(a.lo, c.lo));
+        t_max_hi = __builtin_fminf(t_max_hi, __builtin_fmaxf(a.hi, c.hi));
+        miss = t_max_hi < t_min_lo;
+    }
+    if ((B.flags & BUNDLE_INVY) != 0u) {
+        const Iv inv = {R.ily, R.ihy};
+        const Iv a = iv_mul(Iv{lo1 - B.ohy, lo1 - B.oly}, inv), c = iv_mul(Iv{hi1 - B.ohy, hi1 - B.oly}, inv);
+        t_min_lo = __builtin_fmaxf(t_min_lo, __builtin_fminf(a.lo, c.lo));
+        t_max_hi = __builtin_fminf(t_max_hi, __builtin_fmaxf(a.hi, c.hi));
+        miss = miss | (t_max_hi < t_min_lo);
+    }
+    if ((B.flags & BUNDLE_INVZ) != 0u) {
+        const Iv inv = {R.ilz, R.ihz};
+        const Iv a = iv_mul(Iv{lo2 - B.ohz, lo2 - B.olz}, inv), c = iv_mul(Iv{hi2 - B.ohz, hi2 - B.olz}, inv);
+        t_min_lo = __builtin_fmaxf(t_min_lo, __builtin_fminf(a.lo, c.lo));
+        t_max_hi = __builtin_fminf(t_max_hi, __builtin_fmaxf(a.hi, c.hi));
+        miss = miss | (t_max_hi < t_min_lo);
+    }
+    return !miss;
+}
+
+constexpr uint32_t kListMaxLeaves = 512;    // larger trees keep the hierarchical walk
+
+template <int SLICES>
+__device__ __forceinline__ void trace_list(const TreeView &T, const Ray &r, const bool cull, const bool active, Cand &best,
+                                           SliceCtx &sx, const float exit_t, const uint32_t cidx, const BundleSet &BS) {
+    const uint32_t lane = __lane_id();
+    bool live = active;                                                    // lanes still looking for their closest hit
+    for (uint32_t base = 0; base < T.n_leaves; base += 64u) {
+        const bool have = base + lane < T.n_leaves;
+        const float4 *lp = reinterpret_cast<const float4 *>(T.leaves + (have ? base + lane : 0u));
+        const float4 q0 = lp[0], q1 = lp[1];
+        bool cand = false;
+#pragma unroll
+        for (int k = 0; k < kMaxBundles; ++k) {
+            if ((uint32_t)k < BS.n) {
+                const BundleRegs R = load_bundle(BS.lds, (uint32_t)k);
+                cand = cand | bundle_may_hit_box(R, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+            }
+        }
+        unsigned long long cm = __builtin_amdgcn_ballot_w64(have & cand);
+#ifdef RTK_DEBUG_PHASES
+        sx.n_steps += (uint32_t)__popcll(cm);
+#endif
+        while (cm != 0ull) {
+            const int j = __builtin_ctzll(cm);
+            cm &= cm - 1ull;
+            const float lo0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q0.x), j));
+            const float lo1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q0.y), j));
+            const float lo2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q0.z), j));
+            const float hi0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q0.w), j));
+            const float hi1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q1.x), j));
+            const float hi2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q1.y), j));
+            float t_min;
+            const bool box = slab(lo0, lo1, lo2, hi0, hi1, hi2, r, t_min);
+            const bool pass = live & box & !(best.t < t_min);              // kd_tree_simd.hpp:202-205
+            if (!wave_any(pass)) continue;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(q1.z), j);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(q1.w), j);
+            sx.work += b + 2u;
+#ifdef RTK_DEBUG_PHASES
+            const unsigned long long ph0 = __builtin_readcyclecounter();
+#endif
+            process_leaf<SLICES>(T, a, b, r, cull, pass, cidx, BS, best, sx);
+#ifdef RTK_DEBUG_PHASES
+            {
+                const unsigned long long ph1 = __builtin_readcyclecounter();
+                if (SLICES > 1 && b >= sx.min_tris) { sx.c_big += ph1 - ph0; sx.n_big += 1u; sx.t_big += b; }
+                else { sx.c_small += ph1 - ph0; sx.n_small += 1u; sx.t_small += b; }
+            }
+#endif
+            // occlusion queries: a lane whose hit already answers the query stops; when nobody is left the walk ends
+            if (best.t <= exit_t) live = false;
+            if (!wave_any(live)) return;
+        }
+    }
+}
+
+// The stack walk of kd_tree_simd.hpp:191-228 for the 64 rays of a wave at once (see "Wave-cooperative traversal" above).
 template <bool STATS, int SLICES>
 __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, const bool cull, const bool active,
                                                Cand &best, Stats &st, const uint32_t min_lanes, SliceCtx &sx,
-                                               const float exit_t = -1.0f) {
+                                               const float exit_t, const uint32_t cidx, const BundleSet &BS) {
     const uint32_t end = T.n_nodes;
     uint32_t next = active ? 0u : end;
     uint32_t n = 0;
-    const uint32_t vz = opaque_lane_zero();
-    (void)vz;
-#ifndef RTK_VEC_TREE
     cptr_u32 nodes = (cptr_u32)(const void *)T.nodes;
     NodeS cur = load_node_uniform(nodes);
     uint32_t have = 0u;                                                    // `cur` holds node `have`
-#else
-    // node n is read with two broadcast vector loads; node n+1 (where the walk goes when somebody descends, and
-    // after every leaf) is requested before node n is used, so only the jumps to a skip target wait for memory
-    const char *nodes_b = reinterpret_cast<const char *>(T.nodes);
-    float4 q0 = *reinterpret_cast<const float4 *>(nodes_b + vz);
-    float4 q1 = *reinterpret_cast<const float4 *>(nodes_b + vz + 16);
-    uint32_t have = 0u;                                                    // q0/q1 hold node `have`
-#endif
     while (n < end) {
-#ifndef RTK_VEC_TREE
         // ONE 32-byte scalar load per node (split into "a,b now, box later" by the compiler it cost two serial scalar-cache
         // round trips per step), and the descend-successor n+1 is requested before node n is tested: only a jump to a
         // skip target waits for memory.
@@ -455,21 +755,6 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
         const float lo0 = cur.lo0, lo1 = cur.lo1, lo2 = cur.lo2, hi0 = cur.hi0, hi1 = cur.hi1, hi2 = cur.hi2;
         const uint32_t a = cur.a, b = cur.b;
         cur = ahead; have = n_ahead;
-#else
-        if (have != n) {
-            const char *np = nodes_b + (size_t)n * 32;
-            q0 = *reinterpret_cast<const float4 *>(np + vz);
-            q1 = *reinterpret_cast<const float4 *>(np + vz + 16);
-        }
-        const uint32_t n_ahead = n + 1u < end ? n + 1u : n;
-        const char *np1 = nodes_b + (size_t)n_ahead * 32;
-        const float4 p0 = *reinterpret_cast<const float4 *>(np1 + vz);
-        const float4 p1 = *reinterpret_cast<const float4 *>(np1 + vz + 16);
-        const float lo0 = q0.x, lo1 = q0.y, lo2 = q0.z, hi0 = q0.w, hi1 = q1.x, hi2 = q1.y;
-        const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q1.z));
-        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q1.w));
-        q0 = p0; q1 = p1; have = n_ahead;
-#endif
         const bool part = (next == n);
         const unsigned long long part_mask = __builtin_amdgcn_ballot_w64(part);
         if (part_mask == 0ull) {                                           // nobody is waiting here
@@ -493,44 +778,10 @@ __device__ __forceinline__ uint32_t trace_wave(const TreeView &T, const Ray &r, 
             if (part) next = n + 1;
             if (any_pass) {
                 if (STATS && pass) { st.leaves += 1; st.tris += b; st.packets16 += (b + 15u) >> 4; }
-#ifdef RTK_DEBUG_KHIST
-                const uint32_t k = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(pass));
-                if (STATS && __lane_id() == 0u) {
-                    const uint32_t kb = k <= 2u ? 0u : k <= 4u ? 1u : k <= 8u ? 2u : k <= 16u ? 3u : k <= 32u ? 4u : 5u;
-                    const uint32_t tb = b < 12u ? 0u : b < 64u ? 1u : b < 192u ? 2u : 3u;
-                    atomicAdd(T.khist + tb * 8u + kb, (unsigned long long)b);
-                    atomicAdd(T.khist + 32u + tb * 8u + kb, 1ull);
-                }
-#endif
 #ifdef RTK_DEBUG_PHASES
                 const unsigned long long ph0 = __builtin_readcyclecounter();
 #endif
-                if (SLICES > 1 && b >= sx.min_tris) {
-                    GroupShared *sh = sx.sh;
-                    const uint32_t lane = __lane_id();
-                    if (sx.rays_dirty) {
-                        sh->ray_o[lane] = make_float4(r.o.x, r.o.y, r.o.z, 0.f);
-                        sh->ray_d[lane] = make_float4(r.d.x, r.d.y, r.d.z, 0.f);
-                        sx.ray_gen += 1u;
-                        sx.rays_dirty = false;
-                    }
-                    sh->best_t[lane] = best.t;
-                    const unsigned long long pm = __builtin_amdgcn_ballot_w64(pass), cm = __builtin_amdgcn_ballot_w64(cull);
-                    if (lane == 0u) {
-                        sh->pass_mask = pm; sh->cull_mask = cm;
-                        sh->first = a; sh->count = b; sh->kind = GROUP_LEAF; sh->ray_gen = sx.ray_gen;
-                    }
-                    __syncthreads();                                       // B1: helpers start on their slices
-                    RTK_LEAF_RANGE(T, tris, a, 0u, b / (uint32_t)SLICES, r, cull, pass, best);
-                    __syncthreads();                                       // B2: helper results are in LDS
-#pragma unroll
-                    for (int s = 1; s < SLICES; ++s) {
-                        const float4 c = sh->result[s][lane];
-                        if (c.x < best.t) { best.t = c.x; best.u = c.y; best.v = c.z; best.k = __float_as_uint(c.w); }
-                    }
-                } else {
-                    RTK_LEAF_RANGE(T, tris, a, 0u, b, r, cull, pass, best);
-                }
+                process_leaf<SLICES>(T, a, b, r, cull, pass, cidx, BS, best, sx);
 #ifdef RTK_DEBUG_PHASES
                 {
                     const unsigned long long ph1 = __builtin_readcyclecounter();
@@ -556,22 +807,38 @@ constexpr uint32_t kAutoMinLanes = 12;
 // (is_occluded, render.hpp:110-131, for scenes without transmissive materials).  The lane then stops at the end of
 // the first leaf that gives it such a hit: what it has evaluated up to there is a PREFIX of what the reference
 // evaluates (same order, same pruning), the reference's closest hit can only be nearer, so the answer is the same.
+// `cls` (per lane): the caller's name for the coherent class the lane's ray belongs to (camera rays, shadow rays towards
+// light k, ...); it only steers the bundle culling, never a result.
 template <int MODE, bool STATS, bool LDS_NODES, int SLICES = 1>
 __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_nodes, const Ray &r, const bool cull,
                                       const bool active, Stats &st, SliceCtx &sx, const uint32_t auto_min = kAutoMinLanes,
-                                      const float exit_t = -1.0f) {
+                                      const float exit_t = -1.0f, const uint32_t cls = 0u) {
     Cand best;
     best.t = kFltMax; best.u = 0.0f; best.v = 0.0f; best.k = kMiss;
     sx.rays_dirty = true;
     if (MODE == RTK_TRACE_LANE) {
         trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, active ? 0u : T.n_nodes, best, st, exit_t);
     } else if (MODE == RTK_TRACE_WAVE) {
-        if (wave_any(active)) (void)trace_wave<STATS, SLICES>(T, r, cull, active, best, st, 1u, sx, exit_t);
+        if (wave_any(active)) {
+            // root box first: most traces of a frame end here (background), before anything is spent on bundles
+            cptr_u32 nodes = (cptr_u32)(const void *)T.nodes;
+            const NodeS root = load_node_uniform(nodes);
+            float t_min;
+            const bool in = active & slab(root.lo0, root.lo1, root.lo2, root.hi0, root.hi1, root.hi2, r, t_min);
+            if (STATS || wave_any(in)) {                                    // (the counting build walks every node)
+                BundleSet BS = {sx.bundle_lds, 0u};
+                uint32_t cidx = 0u;
+                if (T.bundle_cull != 0 && sx.bundle_lds != nullptr) BS.n = make_bundles(r, cull, active, cls, sx.bundle_lds, cidx);
+                if (!STATS && BS.n != 0u && T.n_leaves <= kListMaxLeaves) trace_list<SLICES>(T, r, cull, active, best, sx, exit_t, cidx, BS);
+                else (void)trace_wave<STATS, SLICES>(T, r, cull, active, best, st, 1u, sx, exit_t, cidx, BS);
+            }
+        }
     } else {
         const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
         if (am != 0ull) {
             uint32_t next = active ? 0u : T.n_nodes;
-            if ((uint32_t)__popcll(am) >= auto_min) next = trace_wave<STATS, 1>(T, r, cull, active, best, st, auto_min, sx, exit_t);
+            const BundleSet none = {nullptr, 0u};
+            if ((uint32_t)__popcll(am) >= auto_min) next = trace_wave<STATS, 1>(T, r, cull, active, best, st, auto_min, sx, exit_t, 0u, none);
             trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, next, best, st, exit_t);
         }
     }

@@ -343,8 +343,9 @@ def test_auto_engine_trials_on_forking_scenes_keep_the_frame(rtk, ora, scene, de
 def test_streaming_pipeline_queue_overflow_falls_back_to_the_megakernel(rtk, ora, monkeypatch):
     """With room for the camera rays only, every refractive / GI child overflows the node queue: the frame must
     still be exact (redone by the megakernel) and the counters must describe one frame, not two."""
-    acc, oacc = _scene_pair(rtk, ora, SCENE8)
-    monkeypatch.setenv("RTK_STREAM_NODE_FACTOR", "1")
+    _, oacc = _scene_pair(rtk, ora, SCENE8)
+    monkeypatch.setenv("RTK_STREAM_NODE_FACTOR", "1")              # environment knobs are read when an accel is built
+    acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(SCENE8))
     rgb, cn = acc.render_frame(rtk.RenderConfig(width=200, height=120, max_ray_depth=6, trace_mode=FRAME_MODES["stream"]))
     ref, ocn = oacc.render(200, 120, 1, 6, 0)
     assert cn["rays"] == ocn["rays"]

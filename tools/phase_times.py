@@ -16,8 +16,8 @@ p = rtk.RenderConfig(width=w, height=h, trace_mode=mode).to_c()
 rgb = np.zeros((h, w, 3), np.float32); cn = rtk.Counters()
 for _ in range(2): assert dbg.rtk_render_frame(ac, C.byref(p), rgb.ctypes.data, C.byref(cn)) == 0
 # lane i of block (by, bx) wrote value i at pixel (by*8 + i//8, bx*8 + i%8)
-r = rgb[:, :, 0].reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)[:, :14].astype(np.float64)
-names = ["total", "trace", "n_trace", "steps", "n_small", "t_small", "c_small", "n_big", "t_big", "c_big", "prologue", "to_first_trace", "first_trace", "after_first_trace"]
+r = rgb[:, :, 0].reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)[:, :17].astype(np.float64)
+names = ["total", "trace", "n_trace", "steps", "n_small", "t_small", "c_small", "n_big", "t_big", "c_big", "prologue", "to_first_trace", "first_trace", "after_first_trace", "chunks", "surv", "ctris"]
 def show(tag, m):
     s = r[m].sum(0); d = dict(zip(names, s)); n = m.sum()
     c_nodes = d["trace"] - d["c_small"] - d["c_big"]
@@ -26,6 +26,7 @@ def show(tag, m):
     print(f"    per block: traces {d['n_trace']/n:.1f}, node steps {d['steps']/n:.0f} ({c_nodes/max(d['steps'],1):.0f} cyc/step), "
           f"small leaves {d['n_small']/n:.1f} with {d['t_small']/n:.0f} tris ({d['c_small']/max(d['t_small'],1):.0f} cyc/tri), "
           f"sliced leaves {d['n_big']/n:.1f} with {d['t_big']/n:.0f} tris ({d['c_big']/max(d['n_big'],1):.0f} cyc/leaf, {d['c_big']/max(d['t_big'],1):.0f} cyc/tri)")
+    print(f"    owner's bundle culling per block: {d['chunks']/n:.1f} chunks, {d['ctris']/n:.0f} triangles in, {d['surv']/n:.1f} survivors ({100*d['surv']/max(d['ctris'],1):.1f}%)")
 tot = r[:, 0]
 bg = (r[:, 2] == 1) & (r[:, 4] + r[:, 7] == 0)
 print("background blocks (one trace, no leaf):", bg.sum(), "mean cycles: prologue %.0f, ray setup until first trace %.0f, first trace %.0f, after it %.0f; total %.0f"
