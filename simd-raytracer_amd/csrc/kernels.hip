@@ -411,8 +411,15 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
             // they may stop at the first hit that says yes (trace(), `exit_t`; A.shadow_exit is set by the host).
             const float exit_t = (A.shadow_exit && pend == PEND_SHADOW) ? shadow_max_t : -1.0f;
             // ray class for the bundle culling: shadow rays by light, everything else by depth (camera rays = 0)
-            const uint32_t cls = (pend == PEND_SHADOW) ? 0x100u + (uint32_t)light_k : (uint32_t)depth;
-            cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx, kAutoMinLanes, exit_t, cls);
+            // (shadow rays end in their light: the lines of a class pass through that point, the "apex" of a pencil bundle)
+            uint32_t cls = (uint32_t)depth;
+            V3 apex = black;
+            if (pend == PEND_SHADOW) {
+                const DevLight *L = A.lights + light_k;
+                cls = kClsHasApex | (0x100u + (uint32_t)light_k);
+                apex = mk(L->pos[0], L->pos[1], L->pos[2]);
+            }
+            cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx, kAutoMinLanes, exit_t, cls, apex);
 #ifdef RTK_DEBUG_PHASES
             sx.c_trace += __builtin_readcyclecounter() - tr0; sx.n_trace += 1u;
             if (ph_after_first == 0) ph_after_first = __builtin_readcyclecounter();

@@ -401,7 +401,10 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         while (wave_any(pending)) {
             // no transmissive material in the scene: the query may stop at the first hit nearer than the light (trace(), `exit_t`)
             const float exit_t = A.shadow_exit ? max_t : -1.0f;
-            const Cand c = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, false, pending, st, sx, S.auto_min_lanes, exit_t);
+            // every ray of the item ends in light k: a pencil bundle with that apex (trace.hip.hpp); rays that stepped through a
+            // transmissive surface still lie on their line
+            const Cand c = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, false, pending, st, sx, S.auto_min_lanes, exit_t,
+                                                              kClsHasApex | k, mk(L->pos[0], L->pos[1], L->pos[2]));
             if (pending) {
                 nrays += 1u;
                 bool clr = (c.k == kMiss) | (max_t < c.t);                   // :117

@@ -285,18 +285,20 @@ __device__ __forceinline__ void leaf_range_wave(cptr_f32 tris, const uint32_t fi
 //
 // A trace's bundles (at most kMaxBundles, one per ray class the caller names; further classes are merged into the last)
 // live in LDS, kBundleFloats floats each: [0..11] the boxes below, [12..17] bounds of fl(1/d) per axis (lx,hx,ly,hy,lz,hz),
-// [18] flags.  They are read back with the same address in every lane: the values then sit in VGPRs only while a culling
-// pass needs them (neither the SGPR nor the VGPR budget of the render kernels has room for them across a trace).
+// [18] flags, [19] delta * |d|_1, [20..22] apex, [24..38] centre/radius form of the boxes for pencil bundles.  A culling pass
+// reads them back with the same address in every lane and moves them to SGPRs (v_readfirstlane): neither register budget
+// of the render kernels has room for them across a trace, and as VGPRs they crowd out the culling's own temporaries.
 struct Bundle {
     float olx, oly, olz, ohx, ohy, ohz;   // box of the ray origins
     float dlx, dly, dlz, dhx, dhy, dhz;   // box of the ray directions
     uint32_t flags;
 };
-enum : uint32_t { BUNDLE_OK = 1u, BUNDLE_ALL_CULL = 2u, BUNDLE_INVX = 4u, BUNDLE_INVY = 8u, BUNDLE_INVZ = 16u };
+enum : uint32_t { BUNDLE_OK = 1u, BUNDLE_ALL_CULL = 2u, BUNDLE_INVX = 4u, BUNDLE_INVY = 8u, BUNDLE_INVZ = 16u, BUNDLE_PENCIL = 32u };
 constexpr float kBundleLimit = 1.0e9f;   // |coordinate| bound under which the interval arithmetic cannot overflow
 constexpr uint32_t kBundleMinTris = 4;   // leaves (or slices) smaller than this are tested triangle by triangle
 constexpr int kMaxBundles = 3;
-constexpr int kBundleFloats = 20;
+constexpr int kBundleFloats = 40;       // see make_bundles for the layout
+constexpr uint32_t kClsHasApex = 0x80000000u;   // bit of the caller's ray class: the `apex` passed along is meaningful
 
 struct BundleSet {       // wave-uniform handle of the current trace's bundles
     const float *lds;    // [kMaxBundles][kBundleFloats]
@@ -341,16 +343,36 @@ __device__ __forceinline__ Bundle make_bundle(const Ray &r, const bool cull, con
     return B;
 }
 
+// Pencil bundles.  Camera rays leave one point; shadow rays END in one (the light): the LINES of such a bundle pass through
+// a common apex C, up to rounding.  The edge tests of the triangle only depend on the line, so they can be evaluated as if
+// every ray started in C -- a bundle with a point origin, whose bounds are tight (linear in the direction box) no matter
+// how far apart the real origins lie (the two sides of a silhouette, a floor seen at a grazing angle).  The price:
+// tri_step's floats for the real origin differ from the exact value of that formulation by rounding errors, which the
+// culling bounds explicitly (pencil_misses).  The apex is only a HINT from the caller (or found by itself when all origins
+// coincide): every lane measures how far its line really is from C, and that distance `delta` enters the margins, so a
+// wrong hint makes the culling loose, never wrong.
+__device__ __forceinline__ float pencil_delta_lane(const Ray &r, const float cx, const float cy, const float cz) {
+    const float c0 = cx - r.o.x, c1 = cy - r.o.y, c2 = cz - r.o.z;
+    const float dd = (r.d.x * r.d.x + r.d.y * r.d.y) + r.d.z * r.d.z;
+    const float k = ((c0 * r.d.x + c1 * r.d.y) + c2 * r.d.z) / dd;
+    const float w0 = c0 - k * r.d.x, w1 = c1 - k * r.d.y, w2 = c2 - k * r.d.z;
+    const float wn = (__builtin_fabsf(w0) + __builtin_fabsf(w1)) + __builtin_fabsf(w2);
+    const float cn = (__builtin_fabsf(c0) + __builtin_fabsf(c1)) + __builtin_fabsf(c2);
+    const float dl = wn + 1.9073486e-06f * cn;                              // 2^-19 |C - o|_1 covers the rounding of w itself
+    return (dd >= 1.0e-30f) ? dl : __builtin_inff();                          // (a NaN stays a NaN and fails the `<` of the caller)
+}
+
 // Splits the active lanes by `cls` into at most kMaxBundles bundles (classes beyond that join the last one), writes them to
 // `lds` and tells every lane which bundle its ray belongs to.  Returns the number of bundles, 0 when culling is off for this trace.
-__device__ __forceinline__ uint32_t make_bundles(const Ray &r, const bool cull, const bool active, const uint32_t cls, float *lds,
-                                                 uint32_t &cidx) {
+__device__ __forceinline__ uint32_t make_bundles(const Ray &r, const bool cull, const bool active, const uint32_t cls,
+                                                 const V3 apex, float *lds, uint32_t &cidx) {
     const uint32_t lane = __lane_id();
     unsigned long long rem = __builtin_amdgcn_ballot_w64(active);
     uint32_t n = 0u;
     cidx = 0u;
     while (rem != 0ull) {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __builtin_ctzll(rem));
+        const int first = __builtin_ctzll(rem);
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, first);
         const bool mine = ((rem >> lane) & 1ull) != 0ull;
         const bool in = mine & ((n == (uint32_t)(kMaxBundles - 1)) | (cls == c));
         const Bundle B = make_bundle(r, cull, in);
@@ -361,13 +383,47 @@ __device__ __forceinline__ uint32_t make_bundles(const Ray &r, const bool cull, 
         if ((1.0e-30f < B.dlx) | (B.dhx < -1.0e-30f)) flags |= BUNDLE_INVX;
         if ((1.0e-30f < B.dly) | (B.dhy < -1.0e-30f)) flags |= BUNDLE_INVY;
         if ((1.0e-30f < B.dlz) | (B.dhz < -1.0e-30f)) flags |= BUNDLE_INVZ;
+        // apex: the caller's hint (taken from the class's first lane), or the origin itself when all origins coincide
+        float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.x), first));
+        float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.y), first));
+        float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.z), first));
+        bool pencil = (c & kClsHasApex) != 0u;
+        if ((B.olx == B.ohx) & (B.oly == B.ohy) & (B.olz == B.ohz)) { cx = B.olx; cy = B.oly; cz = B.olz; pencil = true; }
+        float delta = 0.0f;
+        if (pencil) {
+            const float dl = pencil_delta_lane(r, cx, cy, cz);
+            const bool bad = in & !(dl < kBundleLimit);                    // NaN-safe: such a lane switches the pencil off
+            delta = wave_minmax<true>(in ? dl : 0.0f) * 1.00001f;
+            const float L = kBundleLimit;
+            pencil = (__builtin_amdgcn_ballot_w64(bad) == 0ull) & (__builtin_fabsf(cx) <= L) & (__builtin_fabsf(cy) <= L) &
+                     (__builtin_fabsf(cz) <= L);
+        }
+        if (pencil) flags |= BUNDLE_PENCIL;
         if (lane == 0u) {
             float4 *q = reinterpret_cast<float4 *>(lds + n * (uint32_t)kBundleFloats);
             q[0] = make_float4(B.olx, B.oly, B.olz, B.ohx);
             q[1] = make_float4(B.ohy, B.ohz, B.dlx, B.dly);
             q[2] = make_float4(B.dlz, B.dhx, B.dhy, B.dhz);
             q[3] = make_float4(1.0f / B.dhx, 1.0f / B.dlx, 1.0f / B.dhy, 1.0f / B.dly);
-            q[4] = make_float4(1.0f / B.dhz, 1.0f / B.dlz, __uint_as_float(flags), 0.0f);
+            // centre / radius of the direction and origin boxes for pencil_misses; the radii are inflated (1 + 1e-6, plus
+            // 2^-22 (|lo| + |hi|)) so that centre +- radius covers the box in exact arithmetic
+            constexpr float kInfl = 1.000001f, kAbs = 2.3841858e-07f;
+            const float dcx = (B.dlx + B.dhx) * 0.5f, dcy = (B.dly + B.dhy) * 0.5f, dcz = (B.dlz + B.dhz) * 0.5f;
+            const float rdx = (B.dhx - B.dlx) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dlx) + __builtin_fabsf(B.dhx));
+            const float rdy = (B.dhy - B.dly) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dly) + __builtin_fabsf(B.dhy));
+            const float rdz = (B.dhz - B.dlz) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dlz) + __builtin_fabsf(B.dhz));
+            const float ocx = (B.olx + B.ohx) * 0.5f, ocy = (B.oly + B.ohy) * 0.5f, ocz = (B.olz + B.ohz) * 0.5f;
+            const float rox = (B.ohx - B.olx) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.olx) + __builtin_fabsf(B.ohx));
+            const float roy = (B.ohy - B.oly) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.oly) + __builtin_fabsf(B.ohy));
+            const float roz = (B.ohz - B.olz) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.olz) + __builtin_fabsf(B.ohz));
+            const float Dmx = __builtin_fabsf(dcx) + rdx, Dmy = __builtin_fabsf(dcy) + rdy, Dmz = __builtin_fabsf(dcz) + rdz;
+            const float dD1 = (delta * ((Dmx + Dmy) + Dmz)) * 1.00001f;                   // delta |d|_1
+            q[4] = make_float4(1.0f / B.dhz, 1.0f / B.dlz, __uint_as_float(flags), dD1);
+            q[5] = make_float4(cx, cy, cz, 0.0f);
+            q[6] = make_float4(dcx, dcy, dcz, rdx);
+            q[7] = make_float4(rdy, rdz, ocx, ocy);
+            q[8] = make_float4(ocz, rox, roy, roz);
+            q[9] = make_float4(Dmx, Dmy, Dmz, 0.0f);
         }
         if (in) cidx = n;
         rem &= ~__builtin_amdgcn_ballot_w64(in);
@@ -376,21 +432,53 @@ __device__ __forceinline__ uint32_t make_bundles(const Ray &r, const bool cull, 
     return n;
 }
 
-struct BundleRegs {      // one bundle read back from LDS (same address in every lane)
+// Bundle images are read back from LDS with the same address in every lane and moved to SGPRs.
+__device__ __forceinline__ float4 lds_uniform4(const float4 *p) {
+    const float4 v = *p;
+    return make_float4(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.x))),
+                       __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.y))),
+                       __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.z))),
+                       __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.w))));
+}
+__device__ __forceinline__ uint32_t bundle_flags(const float *lds, const uint32_t k) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(lds[k * (uint32_t)kBundleFloats + 18u]));
+}
+struct BundleRegs {      // the interval form: boxes + bounds of 1/d
     Bundle b;
     float ilx, ihx, ily, ihy, ilz, ihz;
 };
-__device__ __forceinline__ BundleRegs load_bundle(const float *lds, const uint32_t k) {
+__device__ __forceinline__ BundleRegs load_bundle(const float *lds, const uint32_t k, const bool with_inv) {
     const float4 *q = reinterpret_cast<const float4 *>(lds + k * (uint32_t)kBundleFloats);
-    const float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    const float4 a = lds_uniform4(q), b = lds_uniform4(q + 1), c = lds_uniform4(q + 2);
     BundleRegs R;
     R.b.olx = a.x; R.b.oly = a.y; R.b.olz = a.z; R.b.ohx = a.w;
     R.b.ohy = b.x; R.b.ohz = b.y; R.b.dlx = b.z; R.b.dly = b.w;
     R.b.dlz = c.x; R.b.dhx = c.y; R.b.dhy = c.z; R.b.dhz = c.w;
-    R.ilx = d.x; R.ihx = d.y; R.ily = d.z; R.ihy = d.w;
-    R.ilz = e.x; R.ihz = e.y;
-    R.b.flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(e.z));
+    R.b.flags = bundle_flags(lds, k);
+    R.ilx = R.ihx = R.ily = R.ihy = R.ilz = R.ihz = 0.0f;
+    if (with_inv) {
+        const float4 d = lds_uniform4(q + 3), e = lds_uniform4(q + 4);
+        R.ilx = d.x; R.ihx = d.y; R.ily = d.z; R.ihy = d.w; R.ilz = e.x; R.ihz = e.y;
+    }
     return R;
+}
+struct PencilRegs {      // the centre / radius form (make_bundles)
+    float cx, cy, cz, dD1;
+    float dcx, dcy, dcz, rdx, rdy, rdz, ocx, ocy, ocz, rox, roy, roz, Dmx, Dmy, Dmz;
+    uint32_t flags;
+};
+__device__ __forceinline__ PencilRegs load_pencil(const float *lds, const uint32_t k) {
+    const float4 *q = reinterpret_cast<const float4 *>(lds + k * (uint32_t)kBundleFloats);
+    const float4 e = lds_uniform4(q + 4), f = lds_uniform4(q + 5), g = lds_uniform4(q + 6), h = lds_uniform4(q + 7),
+                 i = lds_uniform4(q + 8), j = lds_uniform4(q + 9);
+    PencilRegs P;
+    P.flags = __float_as_uint(e.z); P.dD1 = e.w;
+    P.cx = f.x; P.cy = f.y; P.cz = f.z;
+    P.dcx = g.x; P.dcy = g.y; P.dcz = g.z; P.rdx = g.w;
+    P.rdy = h.x; P.rdz = h.y; P.ocx = h.z; P.ocy = h.w;
+    P.ocz = i.x; P.rox = i.y; P.roy = i.z; P.roz = i.w;
+    P.Dmx = j.x; P.Dmy = j.y; P.Dmz = j.z;
+    return P;
 }
 
 struct Iv { float lo, hi; };
@@ -409,6 +497,7 @@ __device__ __forceinline__ Iv iv_mul(const Iv a, const Iv b) {                 /
 __device__ __forceinline__ bool bundle_misses(const Bundle &B, const float eps, const float v0x, const float v0y, const float v0z,
                                               const float e1x, const float e1y, const float e1z, const float e2x,
                                               const float e2y, const float e2z) {
+    // (staged with scheduling barriers like pencil_misses: interleaved, the intervals need more registers than the kernels have)
     const Iv dx = {B.dlx, B.dhx}, dy = {B.dly, B.dhy}, dz = {B.dlz, B.dhz};
     // pvec = d x e2, det = e1 . pvec                                             (tri_step: pvx, pvy, pvz, det)
     const Iv pvx = iv_sub(iv_scale(dy, e2z), iv_scale(dz, e2y));
@@ -421,30 +510,113 @@ __device__ __forceinline__ bool bundle_misses(const Bundle &B, const float eps, 
     const bool none = (det.hi < eps) & (all_cull | (-eps < det.lo));              // no ray passes the determinant test
     const bool pos = !(det.hi < eps);                                             // some ray may have det >= eps
     const bool neg = !all_cull & !(-eps < det.lo);                                // some non-culling ray may have det <= -eps
-    // tvec = o - v0, un = tvec . pvec, qvec = tvec x e1, vn = d . qvec, tn = e2 . qvec
+    // one sign of det is left: normalise to det > 0 (x * inv_det == (-x) * (-inv_det) exactly, and fl(1/-d) == -fl(1/d))
+    const float dh = neg ? -det.lo : det.hi;
+    const float dl = __builtin_fmaxf(neg ? -det.hi : det.lo, eps);                // rays with a smaller determinant fail the test above
+    // fl(1/det) for det in [dl, dh]: v_rcp_f32 is within 1 ulp of 1/x, fl(1/x) within 1/2; 8 ulp of slack
+    const float il = __builtin_amdgcn_rcpf(dh) * 0.999999f, ih = __builtin_amdgcn_rcpf(dl) * 1.000001f;
+    __builtin_amdgcn_sched_barrier(0);
+    // tvec = o - v0, un = tvec . pvec
     const Iv tvx = {B.olx - v0x, B.ohx - v0x}, tvy = {B.oly - v0y, B.ohy - v0y}, tvz = {B.olz - v0z, B.ohz - v0z};
     Iv un = iv_add(iv_add(iv_mul(tvx, pvx), iv_mul(tvy, pvy)), iv_mul(tvz, pvz));
+    if (neg) un = Iv{-un.hi, -un.lo};
+    const float u_hi = __builtin_fmaxf(un.hi * il, un.hi * ih), u_lo = __builtin_fminf(un.lo * il, un.lo * ih);
+    bool out = (u_hi < 0.0f) | (1.0f < u_lo);                                     // 0 <= u <= 1           (kd_tree_simd.hpp:47)
+    __builtin_amdgcn_sched_barrier(0);
+    // qvec = tvec x e1, vn = d . qvec, tn = e2 . qvec
     const Iv qx = iv_sub(iv_scale(tvy, e1z), iv_scale(tvz, e1y));
     const Iv qy = iv_sub(iv_scale(tvz, e1x), iv_scale(tvx, e1z));
     const Iv qz = iv_sub(iv_scale(tvx, e1y), iv_scale(tvy, e1x));
+    __builtin_amdgcn_sched_barrier(0);
     Iv vn = iv_add(iv_add(iv_mul(dx, qx), iv_mul(dy, qy)), iv_mul(dz, qz));
-    Iv tn = iv_add(iv_add(iv_scale(qx, e2x), iv_scale(qy, e2y)), iv_scale(qz, e2z));
-    // one sign of det is left: normalise to det > 0 (x * inv_det == (-x) * (-inv_det) exactly, and fl(1/-d) == -fl(1/d))
-    float dl = det.lo, dh = det.hi;
-    if (neg) {
-        dl = -det.hi; dh = -det.lo;
-        un = Iv{-un.hi, -un.lo}; vn = Iv{-vn.hi, -vn.lo}; tn = Iv{-tn.hi, -tn.lo};
-    }
-    dl = __builtin_fmaxf(dl, eps);                                                // rays with a smaller determinant fail the test above
-    // fl(1/det) for det in [dl, dh]: v_rcp_f32 is within 1 ulp of 1/x, fl(1/x) within 1/2; 8 ulp of slack
-    const float il = __builtin_amdgcn_rcpf(dh) * 0.999999f, ih = __builtin_amdgcn_rcpf(dl) * 1.000001f;
-    const float u_hi = __builtin_fmaxf(un.hi * il, un.hi * ih), u_lo = __builtin_fminf(un.lo * il, un.lo * ih);
+    if (neg) vn = Iv{-vn.hi, -vn.lo};
     const float v_hi = __builtin_fmaxf(vn.hi * il, vn.hi * ih), v_lo = __builtin_fminf(vn.lo * il, vn.lo * ih);
+    out = out | (v_hi < 0.0f) | (1.0f < u_lo + v_lo);                             // 0 <= v, u + v <= 1    (:54)
+    __builtin_amdgcn_sched_barrier(0);
+    Iv tn = iv_add(iv_add(iv_scale(qx, e2x), iv_scale(qy, e2y)), iv_scale(qz, e2z));
+    if (neg) tn = Iv{-tn.hi, -tn.lo};
     const float t_hi = __builtin_fmaxf(tn.hi * il, tn.hi * ih);
-    // 0 <= u <= 1, 0 <= v, u + v <= 1, eps < t                                     (kd_tree_simd.hpp:47, :54, :57)
-    const bool out = (u_hi < 0.0f) | (1.0f < u_lo) | (v_hi < 0.0f) | (1.0f < u_lo + v_lo) | (t_hi <= eps);
+    out = out | (t_hi <= eps);                                                    // eps < t               (:57)
     // both signs possible: the bundle straddles the triangle's plane, keep; huge determinants: no bound on 1/det, keep
     return none | (out & !(pos & neg) & (dh < 1.0e30f));
+}
+
+// true: no ray of the PENCIL bundle can pass triangle_packet::intersect for this lane's triangle.
+// With o - C = alpha d + w, w perpendicular to d, |w| <= delta (pencil_delta_lane), in exact arithmetic
+//     un = (o - v0).(d x e2) = d.A + w.(d x e2),   A  = e2 x (C - v0)
+//     vn = d.((o - v0) x e1) = d.Bv + d.(w x e1),  Bv = (C - v0) x e1
+//     det = d.Dv,  Dv = e2 x e1;     tn = e2.((o - v0) x e1) = -(o - v0).Dv
+// are linear in d (tn: in o), so over the direction box dc +- rd (origin box oc +- ro) their ranges are centre +- |X|.r exactly.
+// tri_step's floats differ from these by rounding: forward error analysis of its expression tree (products rounded once, sums
+// of three products twice more) gives |fl(un) - un| <= 6.1 u T_un, T_un = sum_a |tv_a| (|d_b||e2_c| + |d_c||e2_b|), the same with
+// T_vn = sum_a |d_a| (|tv_b||e1_c| + |tv_c||e1_b|), T_tn = sum_a |e2_a| (|tv_b||e1_c| + |tv_c||e1_b|), and 5.1 u T_det,
+// T_det = sum_a |e1_a| (|d_b||e2_c| + |d_c||e2_b|), u = 2^-24; this function's own evaluation of d.A etc. errs by as much with
+// |C - v0| in place of |tv|.  All of it is covered by M = 2^-20 (T(o) + T(C)) plus the delta terms.  The tests then ask for
+// a clear margin: fl(un) < 0 without underflow => u < 0; fl(un) >= fl(det)(1 + 4u) => u > 1; likewise v and u + v;
+// fl(tn) <= 0 => t <= 0 < eps.  tests/cull_model.py mirrors this function line by line; tests/test_bundle_cull_model.py hammers it.
+// (The evaluation is staged, one linear functional after the other with scheduling barriers in between: left to itself
+// the scheduler interleaves all of them and needs ~150 VGPRs, which the render kernels do not have.)
+__device__ __forceinline__ bool pencil_misses(const PencilRegs &R, const float eps, const float v0x, const float v0y, const float v0z,
+                                              const float e1x, const float e1y, const float e1z, const float e2x,
+                                              const float e2y, const float e2z) {
+    constexpr float kT = 9.5367432e-07f;                                         // 2^-20
+    constexpr float kDet = 4.7683716e-07f;                                       // 2^-21
+    const float a1x = __builtin_fabsf(e1x), a1y = __builtin_fabsf(e1y), a1z = __builtin_fabsf(e1z);
+    const float a2x = __builtin_fabsf(e2x), a2y = __builtin_fabsf(e2y), a2z = __builtin_fabsf(e2z);
+    // ---- det = d.Dv
+    const float Px = R.Dmy * a2z + R.Dmz * a2y, Py = R.Dmz * a2x + R.Dmx * a2z, Pz = R.Dmx * a2y + R.Dmy * a2x;    // |d| (x) |e2|
+    const float Dx = e2y * e1z - e2z * e1y, Dy = e2z * e1x - e2x * e1z, Dz = e2x * e1y - e2y * e1x;                  // e2 x e1
+    const float M_det = kT * ((a1x * Px + a1y * Py) + a1z * Pz) + 1.0e-30f;
+    const float c_det = (R.dcx * Dx + R.dcy * Dy) + R.dcz * Dz;
+    const float r_det = (__builtin_fabsf(Dx) * R.rdx + __builtin_fabsf(Dy) * R.rdy) + __builtin_fabsf(Dz) * R.rdz;
+    const float detH = (c_det + r_det) + M_det, detL = (c_det - r_det) - M_det;
+    const bool all_cull = (R.flags & BUNDLE_ALL_CULL) != 0u;
+    const bool none = (detH < eps) & (all_cull | (-eps < detL));                 // no ray passes the determinant test
+    const bool pos = !(detH < eps);
+    const bool neg = !all_cull & !(-eps < detL);
+    const float s = neg ? -1.0f : 1.0f;                                          // normalise to positive determinants
+    const float dH = neg ? -detL : detH;
+    const float rcp = 1.0f / dH;
+    const float slack_d = kDet * dH;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- tn = -(o - v0).Dv over the origin box
+    const float tcx = R.ocx - v0x, tcy = R.ocy - v0y, tcz = R.ocz - v0z;
+    const float TVx = __builtin_fabsf(tcx) + R.rox, TVy = __builtin_fabsf(tcy) + R.roy, TVz = __builtin_fabsf(tcz) + R.roz;
+    const float Qox = TVy * a1z + TVz * a1y, Qoy = TVz * a1x + TVx * a1z, Qoz = TVx * a1y + TVy * a1x;               // |tv| (x) |e1|
+    const float M_tn = kT * ((a2x * Qox + a2y * Qoy) + a2z * Qoz) + 1.0e-30f;
+    const float c_tn = -s * ((tcx * Dx + tcy * Dy) + tcz * Dz);
+    const float r_tn = (__builtin_fabsf(Dx) * R.rox + __builtin_fabsf(Dy) * R.roy) + __builtin_fabsf(Dz) * R.roz;
+    bool out = ((c_tn + r_tn) + M_tn) < 0.0f;                                     // t <= 0
+    const float T_vn_o = (R.Dmx * Qox + R.Dmy * Qoy) + R.Dmz * Qoz;
+    const float T_un_o = (TVx * Px + TVy * Py) + TVz * Pz;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- un = d.A (+ delta term), un - det = d.X1
+    const float cvx = R.cx - v0x, cvy = R.cy - v0y, cvz = R.cz - v0z;
+    const float TCx = __builtin_fabsf(cvx), TCy = __builtin_fabsf(cvy), TCz = __builtin_fabsf(cvz);
+    const float M_un = kT * (T_un_o + ((TCx * Px + TCy * Py) + TCz * Pz)) + R.dD1 * ((a2x + a2y) + a2z) + 1.0e-30f;
+    const float Ax = e2y * cvz - e2z * cvy, Ay = e2z * cvx - e2x * cvz, Az = e2x * cvy - e2y * cvx;                  // e2 x (C - v0)
+    const float c_un = s * ((R.dcx * Ax + R.dcy * Ay) + R.dcz * Az);
+    const float r_un = (__builtin_fabsf(Ax) * R.rdx + __builtin_fabsf(Ay) * R.rdy) + __builtin_fabsf(Az) * R.rdz;
+    const float unH = (c_un + r_un) + M_un;
+    out = out | ((unH < 0.0f) & ((-unH) * rcp >= 1.0e-30f));                      // u < 0 for every ray (and no underflow to -0)
+    const float X1x = Ax - Dx, X1y = Ay - Dy, X1z = Az - Dz;
+    const float c_x1 = s * ((R.dcx * X1x + R.dcy * X1y) + R.dcz * X1z);
+    const float r_x1 = (__builtin_fabsf(X1x) * R.rdx + __builtin_fabsf(X1y) * R.rdy) + __builtin_fabsf(X1z) * R.rdz;
+    out = out | (((c_x1 - r_x1) - (M_un + M_det) - slack_d) > 0.0f);              // u > 1
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- vn = d.Bv (+ delta term), un + vn - det = d.X2
+    const float Qcx = TCy * a1z + TCz * a1y, Qcy = TCz * a1x + TCx * a1z, Qcz = TCx * a1y + TCy * a1x;               // |C - v0| (x) |e1|
+    const float M_vn = kT * (T_vn_o + ((R.Dmx * Qcx + R.Dmy * Qcy) + R.Dmz * Qcz)) + R.dD1 * ((a1x + a1y) + a1z) + 1.0e-30f;
+    const float Bx = cvy * e1z - cvz * e1y, By = cvz * e1x - cvx * e1z, Bz = cvx * e1y - cvy * e1x;                  // (C - v0) x e1
+    const float c_vn = s * ((R.dcx * Bx + R.dcy * By) + R.dcz * Bz);
+    const float r_vn = (__builtin_fabsf(Bx) * R.rdx + __builtin_fabsf(By) * R.rdy) + __builtin_fabsf(Bz) * R.rdz;
+    const float vnH = (c_vn + r_vn) + M_vn;
+    out = out | ((vnH < 0.0f) & ((-vnH) * rcp >= 1.0e-30f));                      // v < 0
+    const float X2x = X1x + Bx, X2y = X1y + By, X2z = X1z + Bz;
+    const float c_x2 = s * ((R.dcx * X2x + R.dcy * X2y) + R.dcz * X2z);
+    const float r_x2 = (__builtin_fabsf(X2x) * R.rdx + __builtin_fabsf(X2y) * R.rdy) + __builtin_fabsf(X2z) * R.rdz;
+    out = out | (((c_x2 - r_x2) - ((M_un + M_vn) + M_det) - slack_d) > 0.0f);     // u + v > 1
+    return none | (out & !(pos & neg) & (dH < 1.0e30f));
 }
 
 // Leaf references [lo, hi) of the leaf starting at `first`, bundle-culled 64 at a time (one triangle per lane), the
@@ -463,20 +635,19 @@ __device__ __forceinline__ void leaf_range_bundle(const float *tris, const uint3
                                                   const uint32_t cidx, const BundleSet &BS, Cand &best RTK_TALLY_ARG) {
     const unsigned long long pass_mask = __builtin_amdgcn_ballot_w64(pass);
     const uint32_t lane = __lane_id();
-    // which bundles have a ray in this leaf at all
-    unsigned long long in_k[kMaxBundles];
-#pragma unroll
-    for (int k = 0; k < kMaxBundles; ++k) in_k[k] = __builtin_amdgcn_ballot_w64(pass & (cidx == (uint32_t)k));
     for (uint32_t base = lo; base < hi; base += 64u) {
         const uint32_t cnt = hi - base < 64u ? hi - base : 64u;
         const bool have = lane < cnt;
         const F3 *tp = reinterpret_cast<const F3 *>(tris + (size_t)(first + base + (have ? lane : 0u)) * 9);
         const F3 v0 = tp[0], e1 = tp[1], e2 = tp[2];
         bool keep = false;
-#pragma unroll
-        for (int k = 0; k < kMaxBundles; ++k) {
-            if ((uint32_t)k < BS.n && in_k[k] != 0ull) {
-                const BundleRegs R = load_bundle(BS.lds, (uint32_t)k);
+        for (uint32_t k = 0; k < BS.n; ++k) {
+            if (__builtin_amdgcn_ballot_w64(pass & (cidx == k)) == 0ull) continue;       // no ray of this bundle is in the leaf
+            if ((bundle_flags(BS.lds, k) & BUNDLE_PENCIL) != 0u) {
+                const PencilRegs R = load_pencil(BS.lds, k);
+                keep = keep | !pencil_misses(R, eps, v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z);
+            } else {
+                const BundleRegs R = load_bundle(BS.lds, k, false);
                 keep = keep | !bundle_misses(R.b, eps, v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z);
             }
         }
@@ -692,7 +863,7 @@ __device__ __forceinline__ void trace_list(const TreeView &T, const Ray &r, cons
 #pragma unroll
         for (int k = 0; k < kMaxBundles; ++k) {
             if ((uint32_t)k < BS.n) {
-                const BundleRegs R = load_bundle(BS.lds, (uint32_t)k);
+                const BundleRegs R = load_bundle(BS.lds, (uint32_t)k, true);
                 cand = cand | bundle_may_hit_box(R, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
             }
         }
@@ -808,11 +979,12 @@ constexpr uint32_t kAutoMinLanes = 12;
 // the first leaf that gives it such a hit: what it has evaluated up to there is a PREFIX of what the reference
 // evaluates (same order, same pruning), the reference's closest hit can only be nearer, so the answer is the same.
 // `cls` (per lane): the caller's name for the coherent class the lane's ray belongs to (camera rays, shadow rays towards
-// light k, ...); it only steers the bundle culling, never a result.
+// light k, ...); with kClsHasApex set, `apex` is a point the lines of the class's rays (should) pass through.  Both only steer
+// the bundle culling, never a result.
 template <int MODE, bool STATS, bool LDS_NODES, int SLICES = 1>
 __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_nodes, const Ray &r, const bool cull,
                                       const bool active, Stats &st, SliceCtx &sx, const uint32_t auto_min = kAutoMinLanes,
-                                      const float exit_t = -1.0f, const uint32_t cls = 0u) {
+                                      const float exit_t = -1.0f, const uint32_t cls = 0u, const V3 apex = V3{0.f, 0.f, 0.f}) {
     Cand best;
     best.t = kFltMax; best.u = 0.0f; best.v = 0.0f; best.k = kMiss;
     sx.rays_dirty = true;
@@ -828,7 +1000,7 @@ __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_node
             if (STATS || wave_any(in)) {                                    // (the counting build walks every node)
                 BundleSet BS = {sx.bundle_lds, 0u};
                 uint32_t cidx = 0u;
-                if (T.bundle_cull != 0 && sx.bundle_lds != nullptr) BS.n = make_bundles(r, cull, active, cls, sx.bundle_lds, cidx);
+                if (T.bundle_cull != 0 && sx.bundle_lds != nullptr) BS.n = make_bundles(r, cull, active, cls, apex, sx.bundle_lds, cidx);
                 if (!STATS && BS.n != 0u && T.n_leaves <= kListMaxLeaves) trace_list<SLICES>(T, r, cull, active, best, sx, exit_t, cidx, BS);
                 else (void)trace_wave<STATS, SLICES>(T, r, cull, active, best, st, 1u, sx, exit_t, cidx, BS);
             }
