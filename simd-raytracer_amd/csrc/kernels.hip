@@ -80,6 +80,48 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
 // diffuse-GI parents keep their partial results in a small per-lane frame stack, evaluated in the same
 // order as the recursion so the floating-point results are identical.
 
+// "Light burst": the occlusion queries of a diffuse hit towards its lights (render.hpp:184-206) are independent of each other.
+// When every lane that is about to query a light is at the SAME light k, the owner posts GROUP_EXTRA and each helper wave
+// traces the whole query of one further light (k + 1, k + 2, ...) on its own -- a single-class pencil bundle per wave, no
+// slicing -- while the owner traces light k (and whatever other rays its lanes have pending).  The owner then adds the
+// contributions in light order, so the float sums are those of the sequential loop.  Four dependent traces become one step.
+// Scenes with transmissive materials keep the sequential loop (a query there may need several segments).
+template <int SLICES>
+struct ShadowBurstService {
+    const RenderArgs &A;
+    __device__ __forceinline__ void operator()(GroupShared *sh, const uint32_t slice) const {
+        const uint32_t lane = __lane_id();
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->first) + slice;     // this wave's light
+        const unsigned long long mask = sh->pass_mask;
+        float contrib = 0.0f;
+        bool clear = true;
+        uint32_t n = 0u;
+        if (k < (uint32_t)A.n_lights) {
+            const float PI_F = 3.14159265358979323846f;
+            const float4 a = sh->ray_o[lane], b = sh->ray_d[lane];
+            const V3 P = mk(a.x, a.y, a.z), ncos = mk(a.w, b.x, b.y);
+            const DevLight *L = A.lights + k;                                // wave-uniform
+            const V3 lp = mk(L->pos[0], L->pos[1], L->pos[2]);
+            V3 ld = lp - P;                                                  // the light loop body of k_render's ST_LIGHT, verbatim
+            const float radius = length(ld);
+            const float area = 4.0f * PI_F * radius * radius;
+            ld = normalized(ld);
+            const float d0 = dot(ld, ncos);
+            const float cosine = (0.0f < d0) ? d0 : 0.0f;
+            contrib = (L->intensity / area) * cosine;
+            const bool q = (((mask >> lane) & 1ull) != 0ull) & (0.0f < radius);    // is_occluded's loop guard, render.hpp:114
+            const Ray ray = make_ray(P + (A.shadow_bias * ld), ld);
+            Stats st = {0, 0, 0, 0, 0, 0};
+            SliceCtx sx = {nullptr, 0xFFFFFFFFu, 0u, true, 0u, group_private_bundles<SLICES>(sh, slice)};
+            const float exit_t = A.shadow_exit ? radius : -1.0f;
+            const Cand c = trace<RTK_TRACE_WAVE, false, false, 1>(A.tree, nullptr, ray, false, q, st, sx, kAutoMinLanes, exit_t,
+                                                                  kClsHasApex | (0x100u + k), lp);
+            if (q) { clear = (c.k == kMiss) | (radius < c.t); n = 1u; }     // render.hpp:117
+        }
+        sh->result[slice][lane] = make_float4(contrib, clear ? 1.0f : 0.0f, __uint_as_float(n), 0.0f);
+    }
+};
+
 enum : int { ST_NEW_SAMPLE = 0, ST_TRACE, ST_SHADE, ST_LIGHT, ST_RETURN, ST_DONE };
 enum : int { PEND_CHILD_BG = 0, PEND_CHILD_BLACK = 1, PEND_SHADOW = 2 };
 enum : uint32_t { FR_REFR_A = 0, FR_REFR_B = 1, FR_DIFFUSE = 2 };
@@ -99,6 +141,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     // camera ray's hit is read from A.prim instead of being traced again
 #ifdef RTK_DEBUG_PHASES
     const unsigned long long ph_entry = __builtin_readcyclecounter();
+    const unsigned long long ph_rt0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz, the same clock on every CU
 #endif
     if (PRIMED && blockIdx.x >= *A.n_listed) return;
     if (A.only_if != nullptr && *A.only_if == 0u) return;        // fallback launch behind the streaming pipeline: nothing overflowed
@@ -140,7 +183,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         gwave = (A.order_in != nullptr && unit < A.n_units) ? A.order_in[unit] : unit;
     }
     if (SLICES > 1 && slice != 0u) {                 // helper waves (trace.hip.hpp, "Workgroup-cooperative leaves")
-        group_helper_loop<SLICES>(A.tree, group_sh, slice);
+        group_helper_loop<SLICES>(A.tree, group_sh, slice, ShadowBurstService<SLICES>{A});
         return;
     }
     // bundles of the current trace (trace.hip.hpp "Bundle culling"): in the group's shared block when helpers must see them,
@@ -192,6 +235,9 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     Cand cand;
     cand.t = kFltMax; cand.u = cand.v = 0.f; cand.k = kMiss;
     bool primed = false;
+    bool burst_done = false;                 // the trace of this iteration ran as a light burst (wave-uniform)
+    uint32_t burst_base = 0u;
+    unsigned long long burst_lanes = 0ull;
 #ifdef RTK_DEBUG_PHASES
     unsigned long long ph_first_trace = 0, ph_after_first = 0;
 #endif
@@ -402,6 +448,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 nrays -= 1;                                                 // counted by the first pass
             }
             primed = false;
+            burst_done = false;
         } else {
 #ifdef RTK_DEBUG_PHASES
             const unsigned long long tr0 = __builtin_readcyclecounter();
@@ -416,10 +463,34 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
             V3 apex = black;
             if (pend == PEND_SHADOW) {
                 const DevLight *L = A.lights + light_k;
-                cls = kClsHasApex | (0x100u + (uint32_t)light_k);
+                cls = kClsHasApex | (0x100u + (uint32_t)light_k + 0x40u * (uint32_t)depth);   // (different depths: different surfaces)
                 apex = mk(L->pos[0], L->pos[1], L->pos[2]);
             }
+            // light burst (ShadowBurstService): every lane about to query a light is at the same light, and more lights follow
+            bool burst = false;
+            uint32_t burst_k = 0u;
+            unsigned long long burst_mask = 0ull;
+            if (SLICES > 1 && !STATS && !light && A.has_refractive == 0) {
+                const bool sh_lane = need & (pend == PEND_SHADOW);
+                burst_mask = __builtin_amdgcn_ballot_w64(sh_lane);
+                if (burst_mask != 0ull) {
+                    burst_k = (uint32_t)__builtin_amdgcn_readlane(light_k, __builtin_ctzll(burst_mask));
+                    burst = (__builtin_amdgcn_ballot_w64(sh_lane & ((uint32_t)light_k != burst_k)) == 0ull) & (burst_k + 1u < (uint32_t)A.n_lights);
+                }
+            }
+            if (burst) {
+                group_sh->ray_o[lane] = make_float4(P.x, P.y, P.z, ncos.x);
+                group_sh->ray_d[lane] = make_float4(ncos.y, ncos.z, 0.f, 0.f);
+                if (lane == 0u) { group_sh->pass_mask = burst_mask; group_sh->first = burst_k; group_sh->kind = GROUP_EXTRA; }
+                __syncthreads();                                            // B1: the helpers start on their lights
+                sx.min_tris = 0xFFFFFFFFu;                                  // (they are busy: the owner's own leaves stay whole)
+            }
             cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx, kAutoMinLanes, exit_t, cls, apex);
+            if (burst) {
+                __syncthreads();                                            // B2: their answers are in LDS
+                sx.min_tris = A.slice_min_tris;
+            }
+            burst_done = burst; burst_base = burst_k; burst_lanes = burst_mask;
 #ifdef RTK_DEBUG_PHASES
             sx.c_trace += __builtin_readcyclecounter() - tr0; sx.n_trace += 1u;
             if (ph_after_first == 0) ph_after_first = __builtin_readcyclecounter();
@@ -453,6 +524,18 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                     if (clear) acc = acc + (contrib * albedo);               // :205
                     light_k += 1;
                     state = ST_LIGHT;
+                    if (SLICES > 1 && burst_done && ((burst_lanes >> lane) & 1ull) != 0ull) {
+                        // the helpers' lights, in light order: the same float sum as the sequential loop
+#pragma unroll
+                        for (int s = 1; s < SLICES; ++s) {
+                            if (burst_base + (uint32_t)s < (uint32_t)A.n_lights) {
+                                const float4 res = group_sh->result[s][lane];
+                                if (res.y != 0.0f) acc = acc + (res.x * albedo);
+                                nrays += __float_as_uint(res.z);
+                                light_k += 1;
+                            }
+                        }
+                    }
                 }
             } else if (!hit) {
                 ret = (pend == PEND_CHILD_BG) ? background : black;
@@ -472,12 +555,14 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
 #ifdef RTK_DEBUG_PHASES
     if (valid && writer) {
         const unsigned long long ph_now = __builtin_readcyclecounter();
-        const float vals[17] = {(float)(ph_now - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
+        const unsigned long long ph_rt1 = __builtin_amdgcn_s_memrealtime();
+        const float vals[20] = {(float)(ph_now - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
                                 (float)sx.n_small, (float)sx.t_small, (float)sx.c_small, (float)sx.n_big, (float)sx.t_big, (float)sx.c_big,
                                 (float)(ph_begin - ph_entry), (float)(ph_first_trace - ph_begin), (float)(ph_after_first - ph_first_trace),
-                                (float)(ph_now - ph_after_first), (float)sx.tally.chunks, (float)sx.tally.surv, (float)sx.tally.tris};
+                                (float)(ph_now - ph_after_first), (float)sx.tally.chunks, (float)sx.tally.surv, (float)sx.tally.tris,
+                                (float)(ph_rt0 & 0xFFFFFFull), (float)(ph_rt1 & 0xFFFFFFull), (float)blockIdx.x};
         float v = 0.f;
-        for (int i = 0; i < 17; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
+        for (int i = 0; i < 20; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
         float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
         o[0] = v; o[1] = 0.f; o[2] = 0.f;
     }

@@ -296,7 +296,8 @@ struct Bundle {
 enum : uint32_t { BUNDLE_OK = 1u, BUNDLE_ALL_CULL = 2u, BUNDLE_INVX = 4u, BUNDLE_INVY = 8u, BUNDLE_INVZ = 16u, BUNDLE_PENCIL = 32u };
 constexpr float kBundleLimit = 1.0e9f;   // |coordinate| bound under which the interval arithmetic cannot overflow
 constexpr uint32_t kBundleMinTris = 4;   // leaves (or slices) smaller than this are tested triangle by triangle
-constexpr int kMaxBundles = 3;
+constexpr int kMaxBundles = 4;
+constexpr float kBundleSplitRadius = 0.03f;   // a pencil whose direction box is wider than this (per axis, half width) is cut in two
 constexpr int kBundleFloats = 40;       // see make_bundles for the layout
 constexpr uint32_t kClsHasApex = 0x80000000u;   // bit of the caller's ray class: the `apex` passed along is meaningful
 
@@ -362,8 +363,68 @@ __device__ __forceinline__ float pencil_delta_lane(const Ray &r, const float cx,
     return (dd >= 1.0e-30f) ? dl : __builtin_inff();                          // (a NaN stays a NaN and fails the `<` of the caller)
 }
 
-// Splits the active lanes by `cls` into at most kMaxBundles bundles (classes beyond that join the last one), writes them to
-// `lds` and tells every lane which bundle its ray belongs to.  Returns the number of bundles, 0 when culling is off for this trace.
+// Bounds + pencil data of the rays of the lanes with `in`, written to bundle slot `n` of `lds`.  Returns the flags (0 = not OK).
+__device__ __forceinline__ uint32_t emit_bundle(const Ray &r, const bool cull, const bool in, const bool hinted, float cx, float cy,
+                                                float cz, float *lds, const uint32_t n, float &widest, uint32_t &widest_axis,
+                                                float &widest_mid) {
+    const Bundle B = make_bundle(r, cull, in);
+    widest = 0.0f; widest_axis = 0u; widest_mid = 0.0f;
+    if ((B.flags & BUNDLE_OK) == 0u) return 0u;
+    // fl(1/d) per axis: 1/d is monotone decreasing on either side of zero, and so is its rounding; directions with a
+    // tiny or zero component anywhere in the bundle give no bound on that axis (and could overflow the products)
+    uint32_t flags = B.flags;
+    if ((1.0e-30f < B.dlx) | (B.dhx < -1.0e-30f)) flags |= BUNDLE_INVX;
+    if ((1.0e-30f < B.dly) | (B.dhy < -1.0e-30f)) flags |= BUNDLE_INVY;
+    if ((1.0e-30f < B.dlz) | (B.dhz < -1.0e-30f)) flags |= BUNDLE_INVZ;
+    // apex: the caller's hint, or the origin itself when all origins coincide
+    bool pencil = hinted;
+    if ((B.olx == B.ohx) & (B.oly == B.ohy) & (B.olz == B.ohz)) { cx = B.olx; cy = B.oly; cz = B.olz; pencil = true; }
+    float delta = 0.0f;
+    if (pencil) {
+        const float dl = pencil_delta_lane(r, cx, cy, cz);
+        const bool bad = in & !(dl < kBundleLimit);                        // NaN-safe: such a lane switches the pencil off
+        delta = wave_minmax<true>(in ? dl : 0.0f) * 1.00001f;
+        const float L = kBundleLimit;
+        pencil = (__builtin_amdgcn_ballot_w64(bad) == 0ull) & (__builtin_fabsf(cx) <= L) & (__builtin_fabsf(cy) <= L) &
+                 (__builtin_fabsf(cz) <= L);
+    }
+    if (pencil) flags |= BUNDLE_PENCIL;
+    // centre / radius of the direction and origin boxes for pencil_misses; the radii are inflated (1 + 1e-6, plus
+    // 2^-22 (|lo| + |hi|)) so that centre +- radius covers the box in exact arithmetic
+    constexpr float kInfl = 1.000001f, kAbs = 2.3841858e-07f;
+    const float dcx = (B.dlx + B.dhx) * 0.5f, dcy = (B.dly + B.dhy) * 0.5f, dcz = (B.dlz + B.dhz) * 0.5f;
+    const float rdx = (B.dhx - B.dlx) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dlx) + __builtin_fabsf(B.dhx));
+    const float rdy = (B.dhy - B.dly) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dly) + __builtin_fabsf(B.dhy));
+    const float rdz = (B.dhz - B.dlz) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dlz) + __builtin_fabsf(B.dhz));
+    widest = rdx; widest_mid = dcx;
+    if (widest < rdy) { widest = rdy; widest_axis = 1u; widest_mid = dcy; }
+    if (widest < rdz) { widest = rdz; widest_axis = 2u; widest_mid = dcz; }
+    if (__lane_id() == 0u) {
+        float4 *q = reinterpret_cast<float4 *>(lds + n * (uint32_t)kBundleFloats);
+        q[0] = make_float4(B.olx, B.oly, B.olz, B.ohx);
+        q[1] = make_float4(B.ohy, B.ohz, B.dlx, B.dly);
+        q[2] = make_float4(B.dlz, B.dhx, B.dhy, B.dhz);
+        q[3] = make_float4(1.0f / B.dhx, 1.0f / B.dlx, 1.0f / B.dhy, 1.0f / B.dly);
+        const float ocx = (B.olx + B.ohx) * 0.5f, ocy = (B.oly + B.ohy) * 0.5f, ocz = (B.olz + B.ohz) * 0.5f;
+        const float rox = (B.ohx - B.olx) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.olx) + __builtin_fabsf(B.ohx));
+        const float roy = (B.ohy - B.oly) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.oly) + __builtin_fabsf(B.ohy));
+        const float roz = (B.ohz - B.olz) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.olz) + __builtin_fabsf(B.ohz));
+        const float Dmx = __builtin_fabsf(dcx) + rdx, Dmy = __builtin_fabsf(dcy) + rdy, Dmz = __builtin_fabsf(dcz) + rdz;
+        const float dD1 = (delta * ((Dmx + Dmy) + Dmz)) * 1.00001f;                   // delta |d|_1
+        q[4] = make_float4(1.0f / B.dhz, 1.0f / B.dlz, __uint_as_float(flags), dD1);
+        q[5] = make_float4(cx, cy, cz, 0.0f);
+        q[6] = make_float4(dcx, dcy, dcz, rdx);
+        q[7] = make_float4(rdy, rdz, ocx, ocy);
+        q[8] = make_float4(ocz, rox, roy, roz);
+        q[9] = make_float4(Dmx, Dmy, Dmz, 0.0f);
+    }
+    return flags;
+}
+
+// Splits the active lanes by `cls` into at most kMaxBundles bundles (classes beyond that join the last one; a pencil whose
+// directions spread widely -- the two sides of a silhouette -- is cut in two along its widest direction axis while slots are
+// left), writes them to `lds` and tells every lane which bundle its ray belongs to.  Returns the number of bundles, 0 when
+// culling is off for this trace.
 __device__ __forceinline__ uint32_t make_bundles(const Ray &r, const bool cull, const bool active, const uint32_t cls,
                                                  const V3 apex, float *lds, uint32_t &cidx) {
     const uint32_t lane = __lane_id();
@@ -375,58 +436,33 @@ __device__ __forceinline__ uint32_t make_bundles(const Ray &r, const bool cull, 
         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, first);
         const bool mine = ((rem >> lane) & 1ull) != 0ull;
         const bool in = mine & ((n == (uint32_t)(kMaxBundles - 1)) | (cls == c));
-        const Bundle B = make_bundle(r, cull, in);
-        if ((B.flags & BUNDLE_OK) == 0u) return 0u;
-        // fl(1/d) per axis: 1/d is monotone decreasing on either side of zero, and so is its rounding; directions with a
-        // tiny or zero component anywhere in the bundle give no bound on that axis (and could overflow the products)
-        uint32_t flags = B.flags;
-        if ((1.0e-30f < B.dlx) | (B.dhx < -1.0e-30f)) flags |= BUNDLE_INVX;
-        if ((1.0e-30f < B.dly) | (B.dhy < -1.0e-30f)) flags |= BUNDLE_INVY;
-        if ((1.0e-30f < B.dlz) | (B.dhz < -1.0e-30f)) flags |= BUNDLE_INVZ;
-        // apex: the caller's hint (taken from the class's first lane), or the origin itself when all origins coincide
-        float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.x), first));
-        float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.y), first));
-        float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.z), first));
-        bool pencil = (c & kClsHasApex) != 0u;
-        if ((B.olx == B.ohx) & (B.oly == B.ohy) & (B.olz == B.ohz)) { cx = B.olx; cy = B.oly; cz = B.olz; pencil = true; }
-        float delta = 0.0f;
-        if (pencil) {
-            const float dl = pencil_delta_lane(r, cx, cy, cz);
-            const bool bad = in & !(dl < kBundleLimit);                    // NaN-safe: such a lane switches the pencil off
-            delta = wave_minmax<true>(in ? dl : 0.0f) * 1.00001f;
-            const float L = kBundleLimit;
-            pencil = (__builtin_amdgcn_ballot_w64(bad) == 0ull) & (__builtin_fabsf(cx) <= L) & (__builtin_fabsf(cy) <= L) &
-                     (__builtin_fabsf(cz) <= L);
-        }
-        if (pencil) flags |= BUNDLE_PENCIL;
-        if (lane == 0u) {
-            float4 *q = reinterpret_cast<float4 *>(lds + n * (uint32_t)kBundleFloats);
-            q[0] = make_float4(B.olx, B.oly, B.olz, B.ohx);
-            q[1] = make_float4(B.ohy, B.ohz, B.dlx, B.dly);
-            q[2] = make_float4(B.dlz, B.dhx, B.dhy, B.dhz);
-            q[3] = make_float4(1.0f / B.dhx, 1.0f / B.dlx, 1.0f / B.dhy, 1.0f / B.dly);
-            // centre / radius of the direction and origin boxes for pencil_misses; the radii are inflated (1 + 1e-6, plus
-            // 2^-22 (|lo| + |hi|)) so that centre +- radius covers the box in exact arithmetic
-            constexpr float kInfl = 1.000001f, kAbs = 2.3841858e-07f;
-            const float dcx = (B.dlx + B.dhx) * 0.5f, dcy = (B.dly + B.dhy) * 0.5f, dcz = (B.dlz + B.dhz) * 0.5f;
-            const float rdx = (B.dhx - B.dlx) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dlx) + __builtin_fabsf(B.dhx));
-            const float rdy = (B.dhy - B.dly) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dly) + __builtin_fabsf(B.dhy));
-            const float rdz = (B.dhz - B.dlz) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dlz) + __builtin_fabsf(B.dhz));
-            const float ocx = (B.olx + B.ohx) * 0.5f, ocy = (B.oly + B.ohy) * 0.5f, ocz = (B.olz + B.ohz) * 0.5f;
-            const float rox = (B.ohx - B.olx) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.olx) + __builtin_fabsf(B.ohx));
-            const float roy = (B.ohy - B.oly) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.oly) + __builtin_fabsf(B.ohy));
-            const float roz = (B.ohz - B.olz) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.olz) + __builtin_fabsf(B.ohz));
-            const float Dmx = __builtin_fabsf(dcx) + rdx, Dmy = __builtin_fabsf(dcy) + rdy, Dmz = __builtin_fabsf(dcz) + rdz;
-            const float dD1 = (delta * ((Dmx + Dmy) + Dmz)) * 1.00001f;                   // delta |d|_1
-            q[4] = make_float4(1.0f / B.dhz, 1.0f / B.dlz, __uint_as_float(flags), dD1);
-            q[5] = make_float4(cx, cy, cz, 0.0f);
-            q[6] = make_float4(dcx, dcy, dcz, rdx);
-            q[7] = make_float4(rdy, rdz, ocx, ocy);
-            q[8] = make_float4(ocz, rox, roy, roz);
-            q[9] = make_float4(Dmx, Dmy, Dmz, 0.0f);
+        const unsigned long long in_mask = __builtin_amdgcn_ballot_w64(in);
+        const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.x), first));
+        const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.y), first));
+        const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.z), first));
+        const bool hinted = (c & kClsHasApex) != 0u;
+        float widest, mid;
+        uint32_t axis;
+        const uint32_t flags = emit_bundle(r, cull, in, hinted, cx, cy, cz, lds, n, widest, axis, mid);
+        if (flags == 0u) return 0u;
+        rem &= ~in_mask;
+        // room for one more bundle than the classes still waiting need?  then a wide pencil is cut in two
+        const bool room = n + 2u + (rem != 0ull ? 1u : 0u) <= (uint32_t)kMaxBundles;
+        if (room && (flags & BUNDLE_PENCIL) != 0u && widest > kBundleSplitRadius) {
+            const float dv = axis == 0u ? r.d.x : (axis == 1u ? r.d.y : r.d.z);
+            const bool low = in & (dv <= mid), high = in & !(dv <= mid);
+            if (__builtin_amdgcn_ballot_w64(low) != 0ull && __builtin_amdgcn_ballot_w64(high) != 0ull) {
+                float w2, m2;
+                uint32_t a2;
+                if (emit_bundle(r, cull, low, hinted, cx, cy, cz, lds, n, w2, a2, m2) == 0u) return 0u;
+                if (emit_bundle(r, cull, high, hinted, cx, cy, cz, lds, n + 1u, w2, a2, m2) == 0u) return 0u;
+                if (low) cidx = n;
+                if (high) cidx = n + 1u;
+                n += 2u;
+                continue;
+            }
         }
         if (in) cidx = n;
-        rem &= ~__builtin_amdgcn_ballot_w64(in);
         n += 1u;
     }
     return n;
@@ -707,10 +743,20 @@ struct GroupShared {
 static_assert(offsetof(GroupShared, bundles) % 16 == 0, "bundle images are read with 16-byte LDS loads");
 template <int SLICES>
 struct alignas(16) GroupStorage {
-    unsigned char raw[sizeof(GroupShared) + (size_t)SLICES * 64 * sizeof(float4)];
+    // GroupShared, result[SLICES][64], then one private bundle area per wave (helpers that trace on their own, GROUP_EXTRA)
+    unsigned char raw[sizeof(GroupShared) + (size_t)SLICES * 64 * sizeof(float4) + (size_t)SLICES * kMaxBundles * kBundleFloats * sizeof(float)];
     __device__ __forceinline__ GroupShared *get() { return reinterpret_cast<GroupShared *>(raw); }
 };
-enum : uint32_t { GROUP_LEAF = 0, GROUP_EXIT = 1 };
+template <int SLICES>
+__device__ __forceinline__ float *group_private_bundles(GroupShared *sh, const uint32_t slice) {
+    return reinterpret_cast<float *>(&sh->result[SLICES][0]) + slice * (uint32_t)(kMaxBundles * kBundleFloats);
+}
+// commands the owner posts: a leaf to slice, "we are done", or a job for the kernel's own helper service (k_render: the
+// occlusion queries of the other lights, kernels.hip)
+enum : uint32_t { GROUP_LEAF = 0, GROUP_EXIT = 1, GROUP_EXTRA = 2 };
+struct NoExtraService {
+    __device__ __forceinline__ void operator()(GroupShared *, uint32_t) const {}
+};
 
 struct SliceCtx {
     GroupShared *sh;     // LDS (nullptr when SLICES == 1)
@@ -733,9 +779,9 @@ struct SliceCtx {
 #define RTK_SX_TALLY
 #endif
 
-// helper waves: serve leaf slices until the owner posts GROUP_EXIT
-template <int SLICES>
-__device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared *sh, const uint32_t slice) {
+// helper waves: serve leaf slices (and the kernel's extra jobs) until the owner posts GROUP_EXIT
+template <int SLICES, typename Extra = NoExtraService>
+__device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared *sh, const uint32_t slice, const Extra extra = Extra()) {
     const uint32_t lane = __lane_id();
     uint32_t my_gen = 0xFFFFFFFFu;
     Ray r;
@@ -749,6 +795,12 @@ __device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared
         __syncthreads();                                                   // B1: a command is posted
         const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->kind);
         if (kind == GROUP_EXIT) break;
+        if (kind == GROUP_EXTRA) {
+            extra(sh, slice);
+            my_gen = 0xFFFFFFFFu;                                          // ray_o / ray_d carried the job, not rays
+            __syncthreads();                                               // B2
+            continue;
+        }
         const uint32_t gen = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->ray_gen);
         if (gen != my_gen) {
             const float4 o = sh->ray_o[lane], d = sh->ray_d[lane];

@@ -16,8 +16,8 @@ p = rtk.RenderConfig(width=w, height=h, trace_mode=mode).to_c()
 rgb = np.zeros((h, w, 3), np.float32); cn = rtk.Counters()
 for _ in range(2): assert dbg.rtk_render_frame(ac, C.byref(p), rgb.ctypes.data, C.byref(cn)) == 0
 # lane i of block (by, bx) wrote value i at pixel (by*8 + i//8, bx*8 + i%8)
-r = rgb[:, :, 0].reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)[:, :17].astype(np.float64)
-names = ["total", "trace", "n_trace", "steps", "n_small", "t_small", "c_small", "n_big", "t_big", "c_big", "prologue", "to_first_trace", "first_trace", "after_first_trace", "chunks", "surv", "ctris"]
+r = rgb[:, :, 0].reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)[:, :20].astype(np.float64)
+names = ["total", "trace", "n_trace", "steps", "n_small", "t_small", "c_small", "n_big", "t_big", "c_big", "prologue", "to_first_trace", "first_trace", "after_first_trace", "chunks", "surv", "ctris", "rt0", "rt1", "wg"]
 def show(tag, m):
     s = r[m].sum(0); d = dict(zip(names, s)); n = m.sum()
     c_nodes = d["trace"] - d["c_small"] - d["c_big"]
@@ -38,3 +38,18 @@ top = np.zeros(len(tot), bool); top[order[:100]] = True
 show("100 longest", top)
 top = np.zeros(len(tot), bool); top[order[:1000]] = True
 show("1000 longest", top)
+
+# ---- timeline (s_memrealtime, 100 MHz): when blocks start / end, how many owners are running
+t0 = r[:, 17].copy(); t1 = r[:, 18].copy()
+t1 = np.where(t1 < t0, t1 + 2**24, t1)
+base = np.median(t0)
+t0 = np.where(t0 < base - 2**23, t0 + 2**24, t0); t1 = np.where(t1 < base - 2**23, t1 + 2**24, t1)
+t1 -= t0.min(); t0 -= t0.min()
+start, end = t0 / 100.0, t1 / 100.0                      # microseconds
+print("kernel span %.1f us; block durations us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (end.max(), (end - start).mean(), *np.percentile(end - start, [50, 90, 99]), (end - start).max()))
+ts = np.linspace(0, end.max(), 25)
+print("owners running over time:", [int(((start <= t) & (end > t)).sum()) for t in ts])
+last = np.argsort(-end)[:8]
+print("last to finish (end us, start us, duration us, traces, dispatch index):", [(round(float(end[i]), 1), round(float(start[i]), 1), round(float(end[i] - start[i]), 1), int(r[i, 2]), int(r[i, 19])) for i in last])
+longest = np.argsort(-(end - start))[:8]
+print("longest (duration us, start us, traces, dispatch index, block y, block x):", [(round(float(end[i] - start[i]), 1), round(float(start[i]), 1), int(r[i, 2]), int(r[i, 19]), int(i // (w // 8)), int(i % (w // 8))) for i in longest])

@@ -10,7 +10,7 @@ acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(f"{S}/hw09/scene5.crtscene"))
 modes = [int(m) for m in os.environ.get("TC_MODES", "0 7").split()]
 st = torch.cuda.current_stream()
 base = {}
-for world in (1, 2, 4, 8):
+for world in [int(w) for w in os.environ.get("TC_WORLDS", "1 2 4 8").split()]:
     for mode in modes:
         times, rays = [], []
         for rank in range(world):
