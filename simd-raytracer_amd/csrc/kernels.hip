@@ -193,7 +193,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                    (SLICES > 1 && !light) ? group_sh->bundles : wave_bundles[wave_in_wg & 3u]};
     const uint32_t lane = threadIdx.x & 63u;
     // one parking area per wave that can own rays: every wave of a light or SLICES == 1 workgroup, one otherwise
-    __shared__ float park_lds[4][15][64];                                  // light workgroups exist for SLICES == 4 only (api.hip)
+    __shared__ float park_lds[4][18][64];                                  // light workgroups exist for SLICES == 4 only (api.hip)
     const uint32_t park_slot = (SLICES > 1 && !light) ? 0u : (wave_in_wg & 3u);
     const unsigned long long cost_t0 = __builtin_readcyclecounter();
     constexpr bool writer = true;
@@ -235,6 +235,9 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     Cand cand;
     cand.t = kFltMax; cand.u = cand.v = 0.f; cand.k = kMiss;
     bool primed = false;
+    // apex hint of the ray in flight (trace.hip.hpp "Pencil bundles"): camera rays leave the camera; their reflections off a
+    // plane leave the camera's mirror image.  A hint only: wrong or noisy, it loosens the culling and changes no result.
+    V3 mirror_apex = black;
     bool burst_done = false;                 // the trace of this iteration ran as a light burst (wave-uniform)
     uint32_t burst_base = 0u;
     unsigned long long burst_lanes = 0ull;
@@ -250,13 +253,15 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                     const float inv = (float)A.spp;
                     if (writer) {
                         float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
-                        o[0] = pixel_sum.x / inv; o[1] = pixel_sum.y / inv; o[2] = pixel_sum.z / inv;   // render.hpp:72
+                        if (A.spp == 1) { o[0] = pixel_sum.x; o[1] = pixel_sum.y; o[2] = pixel_sum.z; }       // x / 1.0f == x, bit for bit
+                        else { o[0] = pixel_sum.x / inv; o[1] = pixel_sum.y / inv; o[2] = pixel_sum.z / inv; }  // render.hpp:72
                     }
                     state = ST_DONE;
                     continue;
                 }
                 rkey = root_key(seed_hash, pixel, (uint32_t)sample);
                 ray = camera_ray(A, px, py, rkey);
+                mirror_apex = ray.o;
                 cull = true; depth = 0; pend = PEND_CHILD_BG; fsp = 0;
                 primed = PRIMED;
                 state = ST_TRACE;
@@ -270,6 +275,8 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 } else if (kind == RTK_MAT_REFLECTIVE) {                                        // :239-250
                     const V3 rd = din - ((2.0f * dot(din, hn)) * hn);
                     const V3 ro = P + (A.reflection_bias * rd);
+                    // the reflected line leaves the mirror image of the incoming line's apex: as far behind P as that apex was
+                    mirror_apex = P - ((length(P - mirror_apex) / length(rd)) * rd);
                     ray = make_ray(ro, rd);
                     rkey = child_key(rkey, 0u);
                     cull = false; depth += 1; pend = PEND_CHILD_BG;
@@ -431,15 +438,37 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         // resolve pass, never across a trace.  Saying so keeps twelve registers out of the traversal loops (the difference
         // between 5 resident waves per SIMD with scratch spills and 5 without).
         hn = black; fn = black; din = black; ret = black;
+        // Most queries of a frame never enter the tree (background): the root box is tested first, and when no lane passes
+        // nothing else is set up -- no parking, no bundles.
+        constexpr bool kRootFirst = !STATS && MODE == RTK_TRACE_WAVE;
+        const bool in_root = kRootFirst ? enters_root(A.tree, ray, need) : need;
+        // light burst (ShadowBurstService): every lane about to query a light is at the same light, and more lights follow
+        bool burst = false;
+        uint32_t burst_k = 0u;
+        unsigned long long burst_mask = 0ull;
+        if (SLICES > 1 && !STATS && !light && A.has_refractive == 0) {
+            const bool sh_lane = need & (pend == PEND_SHADOW);
+            burst_mask = __builtin_amdgcn_ballot_w64(sh_lane);
+            if (burst_mask != 0ull) {
+                burst_k = (uint32_t)__builtin_amdgcn_readlane(light_k, __builtin_ctzll(burst_mask));
+                burst = (__builtin_amdgcn_ballot_w64(sh_lane & ((uint32_t)light_k != burst_k)) == 0ull) & (burst_k + 1u < (uint32_t)A.n_lights);
+            }
+        }
+        const bool quiet = kRootFirst && !burst && !(PRIMED && wave_any(primed)) && !wave_any(in_root);
+        if (quiet) {
+            cand.t = kFltMax; cand.u = cand.v = 0.f; cand.k = kMiss;
+            burst_done = false;
+        } else {
         // State that is live across the query but not used by it waits in LDS instead of in registers: with it the
         // traversal loops overflow the 96 registers of a 5-waves-per-SIMD build into scratch (measured: a background block
-        // spent more time on scratch reloads than on its rays).  [var][lane] layout: conflict-free, 30 LDS operations per query.
+        // spent more time on scratch reloads than on its rays).  [var][lane] layout: conflict-free, 36 LDS operations per query.
         float *const park = &park_lds[park_slot][0][lane];
         park[0 * 64] = pixel_sum.x; park[1 * 64] = pixel_sum.y; park[2 * 64] = pixel_sum.z;
         park[3 * 64] = acc.x; park[4 * 64] = acc.y; park[5 * 64] = acc.z;
         park[6 * 64] = albedo.x; park[7 * 64] = albedo.y; park[8 * 64] = albedo.z;
         park[9 * 64] = ncos.x; park[10 * 64] = ncos.y; park[11 * 64] = ncos.z;
         park[12 * 64] = P.x; park[13 * 64] = P.y; park[14 * 64] = P.z;
+        park[15 * 64] = mirror_apex.x; park[16 * 64] = mirror_apex.y; park[17 * 64] = mirror_apex.z;
         if (PRIMED && wave_any(primed)) {
             // first iteration of the pass: every pending ray is a camera ray whose hit the first pass already found
             if (need) {
@@ -461,22 +490,11 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
             // (shadow rays end in their light: the lines of a class pass through that point, the "apex" of a pencil bundle)
             uint32_t cls = (uint32_t)depth;
             V3 apex = black;
+            if (pend == PEND_CHILD_BG) { cls |= kClsHasApex; apex = mirror_apex; }      // camera rays and chains of reflections
             if (pend == PEND_SHADOW) {
                 const DevLight *L = A.lights + light_k;
                 cls = kClsHasApex | (0x100u + (uint32_t)light_k + 0x40u * (uint32_t)depth);   // (different depths: different surfaces)
                 apex = mk(L->pos[0], L->pos[1], L->pos[2]);
-            }
-            // light burst (ShadowBurstService): every lane about to query a light is at the same light, and more lights follow
-            bool burst = false;
-            uint32_t burst_k = 0u;
-            unsigned long long burst_mask = 0ull;
-            if (SLICES > 1 && !STATS && !light && A.has_refractive == 0) {
-                const bool sh_lane = need & (pend == PEND_SHADOW);
-                burst_mask = __builtin_amdgcn_ballot_w64(sh_lane);
-                if (burst_mask != 0ull) {
-                    burst_k = (uint32_t)__builtin_amdgcn_readlane(light_k, __builtin_ctzll(burst_mask));
-                    burst = (__builtin_amdgcn_ballot_w64(sh_lane & ((uint32_t)light_k != burst_k)) == 0ull) & (burst_k + 1u < (uint32_t)A.n_lights);
-                }
             }
             if (burst) {
                 group_sh->ray_o[lane] = make_float4(P.x, P.y, P.z, ncos.x);
@@ -485,7 +503,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 __syncthreads();                                            // B1: the helpers start on their lights
                 sx.min_tris = 0xFFFFFFFFu;                                  // (they are busy: the owner's own leaves stay whole)
             }
-            cand = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, cull, need, st, sx, kAutoMinLanes, exit_t, cls, apex);
+            cand = trace<MODE, STATS, kStage, SLICES, kRootFirst>(A.tree, lds_nodes, ray, cull, in_root, st, sx, kAutoMinLanes, exit_t, cls, apex);
             if (burst) {
                 __syncthreads();                                            // B2: their answers are in LDS
                 sx.min_tris = A.slice_min_tris;
@@ -502,6 +520,8 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         albedo = mk(park[6 * 64], park[7 * 64], park[8 * 64]);
         ncos = mk(park[9 * 64], park[10 * 64], park[11 * 64]);
         P = mk(park[12 * 64], park[13 * 64], park[14 * 64]);
+        mirror_apex = mk(park[15 * 64], park[16 * 64], park[17 * 64]);
+        }
 
         // ---------- consume
         if (need) {

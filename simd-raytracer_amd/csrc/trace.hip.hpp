@@ -416,7 +416,7 @@ __device__ __forceinline__ uint32_t emit_bundle(const Ray &r, const bool cull, c
         q[6] = make_float4(dcx, dcy, dcz, rdx);
         q[7] = make_float4(rdy, rdz, ocx, ocy);
         q[8] = make_float4(ocz, rox, roy, roz);
-        q[9] = make_float4(Dmx, Dmy, Dmz, 0.0f);
+        q[9] = make_float4(Dmx, Dmy, Dmz, (Dmx + Dmy) + Dmz);
     }
     return flags;
 }
@@ -500,7 +500,7 @@ __device__ __forceinline__ BundleRegs load_bundle(const float *lds, const uint32
 }
 struct PencilRegs {      // the centre / radius form (make_bundles)
     float cx, cy, cz, dD1;
-    float dcx, dcy, dcz, rdx, rdy, rdz, ocx, ocy, ocz, rox, roy, roz, Dmx, Dmy, Dmz;
+    float dcx, dcy, dcz, rdx, rdy, rdz, ocx, ocy, ocz, rox, roy, roz, D1;
     uint32_t flags;
 };
 __device__ __forceinline__ PencilRegs load_pencil(const float *lds, const uint32_t k) {
@@ -513,7 +513,7 @@ __device__ __forceinline__ PencilRegs load_pencil(const float *lds, const uint32
     P.dcx = g.x; P.dcy = g.y; P.dcz = g.z; P.rdx = g.w;
     P.rdy = h.x; P.rdz = h.y; P.ocx = h.z; P.ocy = h.w;
     P.ocz = i.x; P.rox = i.y; P.roy = i.z; P.roz = i.w;
-    P.Dmx = j.x; P.Dmy = j.y; P.Dmz = j.z;
+    P.D1 = j.w;
     return P;
 }
 
@@ -587,7 +587,8 @@ __device__ __forceinline__ bool bundle_misses(const Bundle &B, const float eps, 
 // of three products twice more) gives |fl(un) - un| <= 6.1 u T_un, T_un = sum_a |tv_a| (|d_b||e2_c| + |d_c||e2_b|), the same with
 // T_vn = sum_a |d_a| (|tv_b||e1_c| + |tv_c||e1_b|), T_tn = sum_a |e2_a| (|tv_b||e1_c| + |tv_c||e1_b|), and 5.1 u T_det,
 // T_det = sum_a |e1_a| (|d_b||e2_c| + |d_c||e2_b|), u = 2^-24; this function's own evaluation of d.A etc. errs by as much with
-// |C - v0| in place of |tv|.  All of it is covered by M = 2^-20 (T(o) + T(C)) plus the delta terms.  The tests then ask for
+// |C - v0| in place of |tv|.  All of it is covered by M = 2^-20 (T(o) + T(C)) plus the delta terms (the T's themselves bounded
+// through norms: sum_a x_a (y_b z_c + y_c z_b) <= |x|_1 |y|_1 max|z|).  The tests then ask for
 // a clear margin: fl(un) < 0 without underflow => u < 0; fl(un) >= fl(det)(1 + 4u) => u > 1; likewise v and u + v;
 // fl(tn) <= 0 => t <= 0 < eps.  tests/cull_model.py mirrors this function line by line; tests/test_bundle_cull_model.py hammers it.
 // (The evaluation is staged, one linear functional after the other with scheduling barriers in between: left to itself
@@ -597,12 +598,14 @@ __device__ __forceinline__ bool pencil_misses(const PencilRegs &R, const float e
                                               const float e2y, const float e2z) {
     constexpr float kT = 9.5367432e-07f;                                         // 2^-20
     constexpr float kDet = 4.7683716e-07f;                                       // 2^-21
+    // The T's are bounded through norms instead of being summed out: sum_a x_a (y_b z_c + y_c z_b) <= |x|_1 |y|_1 max|z|.
     const float a1x = __builtin_fabsf(e1x), a1y = __builtin_fabsf(e1y), a1z = __builtin_fabsf(e1z);
     const float a2x = __builtin_fabsf(e2x), a2y = __builtin_fabsf(e2y), a2z = __builtin_fabsf(e2z);
+    const float E11 = (a1x + a1y) + a1z, E21 = (a2x + a2y) + a2z;
+    const float E1m = __builtin_fmaxf(__builtin_fmaxf(a1x, a1y), a1z), E2m = __builtin_fmaxf(__builtin_fmaxf(a2x, a2y), a2z);
     // ---- det = d.Dv
-    const float Px = R.Dmy * a2z + R.Dmz * a2y, Py = R.Dmz * a2x + R.Dmx * a2z, Pz = R.Dmx * a2y + R.Dmy * a2x;    // |d| (x) |e2|
     const float Dx = e2y * e1z - e2z * e1y, Dy = e2z * e1x - e2x * e1z, Dz = e2x * e1y - e2y * e1x;                  // e2 x e1
-    const float M_det = kT * ((a1x * Px + a1y * Py) + a1z * Pz) + 1.0e-30f;
+    const float M_det = kT * ((E11 * R.D1) * E2m) + 1.0e-30f;
     const float c_det = (R.dcx * Dx + R.dcy * Dy) + R.dcz * Dz;
     const float r_det = (__builtin_fabsf(Dx) * R.rdx + __builtin_fabsf(Dy) * R.rdy) + __builtin_fabsf(Dz) * R.rdz;
     const float detH = (c_det + r_det) + M_det, detL = (c_det - r_det) - M_det;
@@ -617,19 +620,17 @@ __device__ __forceinline__ bool pencil_misses(const PencilRegs &R, const float e
     __builtin_amdgcn_sched_barrier(0);
     // ---- tn = -(o - v0).Dv over the origin box
     const float tcx = R.ocx - v0x, tcy = R.ocy - v0y, tcz = R.ocz - v0z;
-    const float TVx = __builtin_fabsf(tcx) + R.rox, TVy = __builtin_fabsf(tcy) + R.roy, TVz = __builtin_fabsf(tcz) + R.roz;
-    const float Qox = TVy * a1z + TVz * a1y, Qoy = TVz * a1x + TVx * a1z, Qoz = TVx * a1y + TVy * a1x;               // |tv| (x) |e1|
-    const float M_tn = kT * ((a2x * Qox + a2y * Qoy) + a2z * Qoz) + 1.0e-30f;
+    const float TV1 = ((__builtin_fabsf(tcx) + R.rox) + (__builtin_fabsf(tcy) + R.roy)) + (__builtin_fabsf(tcz) + R.roz);   // |tv|_1 bound
+    const float M_tn = kT * ((E21 * TV1) * E1m) + 1.0e-30f;
     const float c_tn = -s * ((tcx * Dx + tcy * Dy) + tcz * Dz);
     const float r_tn = (__builtin_fabsf(Dx) * R.rox + __builtin_fabsf(Dy) * R.roy) + __builtin_fabsf(Dz) * R.roz;
     bool out = ((c_tn + r_tn) + M_tn) < 0.0f;                                     // t <= 0
-    const float T_vn_o = (R.Dmx * Qox + R.Dmy * Qoy) + R.Dmz * Qoz;
-    const float T_un_o = (TVx * Px + TVy * Py) + TVz * Pz;
     __builtin_amdgcn_sched_barrier(0);
     // ---- un = d.A (+ delta term), un - det = d.X1
     const float cvx = R.cx - v0x, cvy = R.cy - v0y, cvz = R.cz - v0z;
-    const float TCx = __builtin_fabsf(cvx), TCy = __builtin_fabsf(cvy), TCz = __builtin_fabsf(cvz);
-    const float M_un = kT * (T_un_o + ((TCx * Px + TCy * Py) + TCz * Pz)) + R.dD1 * ((a2x + a2y) + a2z) + 1.0e-30f;
+    const float TS = TV1 + ((__builtin_fabsf(cvx) + __builtin_fabsf(cvy)) + __builtin_fabsf(cvz));                   // |tv|_1 + |C - v0|_1
+    const float M_un = kT * ((TS * R.D1) * E2m) + R.dD1 * E21 + 1.0e-30f;
+    const float M_vn = kT * ((TS * R.D1) * E1m) + R.dD1 * E11 + 1.0e-30f;
     const float Ax = e2y * cvz - e2z * cvy, Ay = e2z * cvx - e2x * cvz, Az = e2x * cvy - e2y * cvx;                  // e2 x (C - v0)
     const float c_un = s * ((R.dcx * Ax + R.dcy * Ay) + R.dcz * Az);
     const float r_un = (__builtin_fabsf(Ax) * R.rdx + __builtin_fabsf(Ay) * R.rdy) + __builtin_fabsf(Az) * R.rdz;
@@ -641,8 +642,6 @@ __device__ __forceinline__ bool pencil_misses(const PencilRegs &R, const float e
     out = out | (((c_x1 - r_x1) - (M_un + M_det) - slack_d) > 0.0f);              // u > 1
     __builtin_amdgcn_sched_barrier(0);
     // ---- vn = d.Bv (+ delta term), un + vn - det = d.X2
-    const float Qcx = TCy * a1z + TCz * a1y, Qcy = TCz * a1x + TCx * a1z, Qcz = TCx * a1y + TCy * a1x;               // |C - v0| (x) |e1|
-    const float M_vn = kT * (T_vn_o + ((R.Dmx * Qcx + R.Dmy * Qcy) + R.Dmz * Qcz)) + R.dD1 * ((a1x + a1y) + a1z) + 1.0e-30f;
     const float Bx = cvy * e1z - cvz * e1y, By = cvz * e1x - cvx * e1z, Bz = cvx * e1y - cvy * e1x;                  // (C - v0) x e1
     const float c_vn = s * ((R.dcx * Bx + R.dcy * By) + R.dcz * Bz);
     const float r_vn = (__builtin_fabsf(Bx) * R.rdx + __builtin_fabsf(By) * R.rdy) + __builtin_fabsf(Bz) * R.rdz;
@@ -1033,10 +1032,22 @@ constexpr uint32_t kAutoMinLanes = 12;
 // `cls` (per lane): the caller's name for the coherent class the lane's ray belongs to (camera rays, shadow rays towards
 // light k, ...); with kClsHasApex set, `apex` is a point the lines of the class's rays (should) pass through.  Both only steer
 // the bundle culling, never a result.
-template <int MODE, bool STATS, bool LDS_NODES, int SLICES = 1>
+// The root box test of a trace for callers that want to know, before they set anything else up, whether any ray enters the
+// tree at all (most traces of a frame do not: background).  Lanes that fail it can never hit anything.
+__device__ __forceinline__ bool enters_root(const TreeView &T, const Ray &r, const bool active) {
+    cptr_u32 nodes = (cptr_u32)(const void *)T.nodes;
+    const NodeS root = load_node_uniform(nodes);
+    float t_min;
+    return active & slab(root.lo0, root.lo1, root.lo2, root.hi0, root.hi1, root.hi2, r, t_min);
+}
+
+// ROOT_DONE: the caller has applied enters_root() already and passes only those lanes as `active` (never with STATS: the
+// counting build charges the root node to every ray).
+template <int MODE, bool STATS, bool LDS_NODES, int SLICES = 1, bool ROOT_DONE = false>
 __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_nodes, const Ray &r, const bool cull,
                                       const bool active, Stats &st, SliceCtx &sx, const uint32_t auto_min = kAutoMinLanes,
                                       const float exit_t = -1.0f, const uint32_t cls = 0u, const V3 apex = V3{0.f, 0.f, 0.f}) {
+    static_assert(!(ROOT_DONE && STATS), "the counting build walks every node, the root included");
     Cand best;
     best.t = kFltMax; best.u = 0.0f; best.v = 0.0f; best.k = kMiss;
     sx.rays_dirty = true;
@@ -1044,17 +1055,15 @@ __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_node
         trace_lane_from<STATS, LDS_NODES>(T, lds_nodes, r, cull, active ? 0u : T.n_nodes, best, st, exit_t);
     } else if (MODE == RTK_TRACE_WAVE) {
         if (wave_any(active)) {
-            // root box first: most traces of a frame end here (background), before anything is spent on bundles
-            cptr_u32 nodes = (cptr_u32)(const void *)T.nodes;
-            const NodeS root = load_node_uniform(nodes);
-            float t_min;
-            const bool in = active & slab(root.lo0, root.lo1, root.lo2, root.hi0, root.hi1, root.hi2, r, t_min);
-            if (STATS || wave_any(in)) {                                    // (the counting build walks every node)
+            // root box first: most traces of a frame end here (background), before anything is spent on bundles; rays that
+            // miss it take no further part (they cannot hit anything, and would only widen the bundles)
+            const bool in = (ROOT_DONE || STATS) ? active : enters_root(T, r, active);
+            if (wave_any(in)) {
                 BundleSet BS = {sx.bundle_lds, 0u};
                 uint32_t cidx = 0u;
-                if (T.bundle_cull != 0 && sx.bundle_lds != nullptr) BS.n = make_bundles(r, cull, active, cls, apex, sx.bundle_lds, cidx);
-                if (!STATS && BS.n != 0u && T.n_leaves <= kListMaxLeaves) trace_list<SLICES>(T, r, cull, active, best, sx, exit_t, cidx, BS);
-                else (void)trace_wave<STATS, SLICES>(T, r, cull, active, best, st, 1u, sx, exit_t, cidx, BS);
+                if (T.bundle_cull != 0 && sx.bundle_lds != nullptr) BS.n = make_bundles(r, cull, in, cls, apex, sx.bundle_lds, cidx);
+                if (!STATS && BS.n != 0u && T.n_leaves <= kListMaxLeaves) trace_list<SLICES>(T, r, cull, in, best, sx, exit_t, cidx, BS);
+                else (void)trace_wave<STATS, SLICES>(T, r, cull, in, best, st, 1u, sx, exit_t, cidx, BS);
             }
         }
     } else {

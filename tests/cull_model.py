@@ -106,19 +106,17 @@ def pencil_misses(C, delta, ol, oh, dl, dh, all_cull, v0, e1, e2, eps=f32(1e-6))
         TVm = [np.abs(tvc[a]) + ro[a] for a in range(3)]
         TC = [np.abs(cv[a]) for a in range(3)]
         aE1 = [np.abs(E1[a]) for a in range(3)]; aE2 = [np.abs(E2[a]) for a in range(3)]
-        P = _across(Dm, aE2)
-        Qo = _across(TVm, aE1)
-        Qc = _across(TC, aE1)
-        T_un = _dot(TVm, P) + _dot(TC, P)
-        T_det = _dot(aE1, P)
-        T_vn = _dot(Dm, Qo) + _dot(Dm, Qc)
-        T_tn = _dot(aE2, Qo)
         E21 = (aE2[0] + aE2[1]) + aE2[2]
         E11 = (aE1[0] + aE1[1]) + aE1[2]
-        M_un = K_T * T_un + (delta * D1) * E21 * f32(1.00001) + ABS_SLACK
-        M_vn = K_T * T_vn + (delta * D1) * E11 * f32(1.00001) + ABS_SLACK
-        M_det = K_T * T_det + ABS_SLACK
-        M_tn = K_T * T_tn + ABS_SLACK
+        E1m = np.maximum(np.maximum(aE1[0], aE1[1]), aE1[2]); E2m = np.maximum(np.maximum(aE2[0], aE2[1]), aE2[2])
+        # the T's of the error analysis, bounded through norms: sum_a x_a (y_b z_c + y_c z_b) <= |x|_1 |y|_1 max|z|
+        TV1 = (TVm[0] + TVm[1]) + TVm[2]
+        TS = TV1 + ((TC[0] + TC[1]) + TC[2])
+        dD1 = (delta * D1) * f32(1.00001)
+        M_un = K_T * ((TS * D1) * E2m) + dD1 * E21 + ABS_SLACK
+        M_vn = K_T * ((TS * D1) * E1m) + dD1 * E11 + ABS_SLACK
+        M_det = K_T * ((E11 * D1) * E2m) + ABS_SLACK
+        M_tn = K_T * ((E21 * TV1) * E1m) + ABS_SLACK
         c_det = _dot(dc, Dv); r_det = _adot(Dv, rd)
         detH = (c_det + r_det) + M_det
         detL = (c_det - r_det) - M_det
