@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTK_ABI_VERSION 2
+#define RTK_ABI_VERSION 3
 
 /* status codes (reference: intersect is noexcept, miss = nullopt, kd_tree_simd.hpp:188,231;
  * loader throws std::invalid_argument, io/json/loader.hpp:104,127,145,170,190,224) */
@@ -145,6 +145,12 @@ typedef struct {
     int32_t collect_stats;          /* 1 = also count nodes/leaves/triangles per ray, as the reference algorithm visits them
                                      * (slower kernel variant); 2 = count what the production path visits (its occlusion
                                      * queries stop at the first answering hit when no material is transmissive; same frame) */
+    /* Progressive accumulation (the spp loop of render/render.hpp:34-72 cut into passes): render samples
+     * [sample_begin, sample_begin + sample_count) of every pixel.  sample_count == 0: all `spp` samples in one call.
+     * A pass with sample_begin > 0 continues the running per-pixel sum the previous pass left in the output buffer (the
+     * sum stays in sample order, so N passes give the bits of one call); the pass that ends at `spp` divides by spp
+     * (render.hpp:72) and leaves the finished frame.  Until then the buffer holds sums, not colours. */
+    int32_t sample_begin, sample_count;
 } rtk_render_params;
 
 typedef struct {
@@ -212,7 +218,17 @@ int rtk_render_last_counters(rtk_accel *accel, rtk_counters *counters);
 int rtk_tiles_assemble_device(const rtk_accel *accel, const rtk_render_params *p, const float *d_gathered,
                               float *d_rgb, void *hip_stream);
 
+/* The camera rays render_frame spawns (render/render.hpp:35-62), sample `sample` of every pixel, [h][w] in row-major order:
+ * what `ray3<F> ray(camera.position, direction)` at :62 holds.  (Also the generator of the fixed synthetic workload.) */
+int rtk_camera_rays(rtk_accel *accel, const rtk_render_params *p, int32_t sample, rtk_ray *rays /* host [h*w] */);
+int rtk_camera_rays_device(rtk_accel *accel, const rtk_render_params *p, int32_t sample, rtk_ray *d_rays, void *hip_stream);
+
 /* ---- image out: replaces write_ppm (io/image/ppm.hpp:7-25) ---- */
+/* The quantisation of write_ppm on the device: out[i] = uint8(255.999 * clamp(rgb[i], 0, 1)) (ppm.hpp:17-19, the product in
+ * double), n = number of floats.  A finished frame leaves the GPU as 3 bytes per pixel instead of 12. */
+int rtk_frame_to_rgb8_device(const float *d_rgb, size_t n, uint8_t *d_out, void *hip_stream);
+/* the P3 text of write_ppm from such bytes (same output as rtk_format_ppm on the floats) */
+int rtk_format_ppm_rgb8(const uint8_t *rgb8, int32_t width, int32_t height, char *buf, size_t cap, size_t *n);
 int rtk_write_ppm(const float *rgb, int32_t width, int32_t height, const char *path);
 /* returns the byte count in *n; writes at most cap bytes into buf (buf may be NULL to query) */
 int rtk_format_ppm(const float *rgb, int32_t width, int32_t height, char *buf, size_t cap, size_t *n);

@@ -35,7 +35,8 @@ ABI_SYMBOLS = [
     "rtk_accel_build", "rtk_accel_tree_info", "rtk_accel_tree_dump", "rtk_accel_destroy",
     "rtk_accel_intersect", "rtk_accel_intersect_device", "rtk_accel_intersect_stats",
     "rtk_render_output_floats", "rtk_render_frame", "rtk_render_frame_device", "rtk_render_last_counters",
-    "rtk_tiles_assemble_device", "rtk_write_ppm", "rtk_format_ppm",
+    "rtk_tiles_assemble_device", "rtk_camera_rays", "rtk_camera_rays_device",
+    "rtk_frame_to_rgb8_device", "rtk_format_ppm_rgb8", "rtk_write_ppm", "rtk_format_ppm",
 ]
 
 
@@ -98,7 +99,8 @@ class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_ray_depth", C.c_int32),
                 ("diffuse_rays", C.c_int32), ("seed", C.c_uint32), ("fov_degrees", C.c_double),
                 ("shadow_bias", C.c_float), ("reflection_bias", C.c_float), ("refraction_bias", C.c_float),
-                ("trace_mode", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("collect_stats", C.c_int32)]
+                ("trace_mode", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("collect_stats", C.c_int32),
+                ("sample_begin", C.c_int32), ("sample_count", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -137,6 +139,10 @@ _L.rtk_render_frame.argtypes = [_vp, C.POINTER(RenderParams), _vp, C.POINTER(Cou
 _L.rtk_render_frame_device.argtypes = [_vp, C.POINTER(RenderParams), _vp, _vp]
 _L.rtk_render_last_counters.argtypes = [_vp, C.POINTER(Counters)]
 _L.rtk_tiles_assemble_device.argtypes = [_vp, C.POINTER(RenderParams), _vp, _vp, _vp]
+_L.rtk_camera_rays.argtypes = [_vp, C.POINTER(RenderParams), C.c_int32, _vp]
+_L.rtk_camera_rays_device.argtypes = [_vp, C.POINTER(RenderParams), C.c_int32, _vp, _vp]
+_L.rtk_frame_to_rgb8_device.argtypes = [_vp, C.c_size_t, _vp, _vp]
+_L.rtk_format_ppm_rgb8.argtypes = [_vp, C.c_int32, C.c_int32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]
 _L.rtk_write_ppm.argtypes = [_vp, C.c_int32, C.c_int32, C.c_char_p]
 _L.rtk_format_ppm.argtypes = [_vp, C.c_int32, C.c_int32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]
 
@@ -278,12 +284,14 @@ class RenderConfig:
     rank: int = 0
     world_size: int = 1
     collect_stats: int = 0     # 1 (or True): per-ray work counters of the reference algorithm; 2: of the production path (early-exit occlusion queries)
+    sample_begin: int = 0      # progressive accumulation: this call renders samples [sample_begin, sample_begin + sample_count)
+    sample_count: int = 0      # 0 = all spp samples in one call
 
     def to_c(self) -> RenderParams:
         return RenderParams(self.width, self.height, self.spp, self.max_ray_depth, self.diffuse_rays, self.seed,
                             self.fov_degrees, np.float32(self.shadow_bias), np.float32(self.reflection_bias),
                             np.float32(self.refraction_bias), self.trace_mode, self.rank, self.world_size,
-                            int(self.collect_stats))
+                            int(self.collect_stats), self.sample_begin, self.sample_count)
 
 
 class KdTreeSimdAccel:
@@ -358,6 +366,19 @@ class KdTreeSimdAccel:
         _check(_L.rtk_render_last_counters(self._h, C.byref(c)))
         return c.as_dict()
 
+    def camera_rays(self, cfg: RenderConfig, sample: int = 0) -> np.ndarray:
+        """[h, w, 6] float32: origin + direction of every pixel's camera ray for sample `sample` (render.hpp:35-62)."""
+        w = cfg.width or self.scene.info.width
+        h = cfg.height or self.scene.info.height
+        rays = np.zeros((h, w, 6), np.float32)
+        p = cfg.to_c()
+        _check(_L.rtk_camera_rays(self._h, C.byref(p), sample, rays.ctypes.data))
+        return rays
+
+    def camera_rays_device(self, cfg: RenderConfig, d_rays_ptr: int, sample: int = 0, stream: int = 0) -> None:
+        p = cfg.to_c()
+        _check(_L.rtk_camera_rays_device(self._h, C.byref(p), sample, d_rays_ptr, stream))
+
     def assemble_device(self, cfg: RenderConfig, d_gathered_ptr: int, d_rgb_ptr: int, stream: int = 0) -> None:
         p = cfg.to_c()
         _check(_L.rtk_tiles_assemble_device(self._h, C.byref(p), d_gathered_ptr, d_rgb_ptr, stream))
@@ -380,6 +401,21 @@ def format_ppm(rgb: np.ndarray) -> bytes:
     _check(_L.rtk_format_ppm(rgb.ctypes.data, w, h, None, 0, C.byref(n)))
     buf = C.create_string_buffer(n.value)
     _check(_L.rtk_format_ppm(rgb.ctypes.data, w, h, buf, n.value, C.byref(n)))
+    return buf.raw[: n.value]
+
+
+def frame_to_rgb8_device(d_rgb_ptr: int, n_floats: int, d_out_ptr: int, stream: int = 0) -> None:
+    """uint8(255.999 * clamp(c, 0, 1)) per channel on the device (io/image/ppm.hpp:17-19)."""
+    _check(_L.rtk_frame_to_rgb8_device(d_rgb_ptr, n_floats, d_out_ptr, stream))
+
+
+def format_ppm_rgb8(rgb8: np.ndarray) -> bytes:
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    h, w, _ = rgb8.shape
+    n = C.c_size_t(0)
+    _check(_L.rtk_format_ppm_rgb8(rgb8.ctypes.data, w, h, None, 0, C.byref(n)))
+    buf = C.create_string_buffer(n.value)
+    _check(_L.rtk_format_ppm_rgb8(rgb8.ctypes.data, w, h, buf, n.value, C.byref(n)))
     return buf.raw[: n.value]
 
 

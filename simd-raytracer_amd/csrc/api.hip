@@ -230,6 +230,7 @@ bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || 
 struct FrameGeom {
     uint32_t width, height, bucket, tiles_x, tiles_y, n_buckets, blocks_side, buckets_per_rank;
     int rank, world;
+    int sample_begin, sample_end;      // this call renders samples [sample_begin, sample_end) (rtk_render_params.sample_begin/_count)
 };
 
 int frame_geom(const rtk_accel *a, const rtk_render_params *p, FrameGeom &g) {
@@ -242,6 +243,12 @@ int frame_geom(const rtk_accel *a, const rtk_render_params *p, FrameGeom &g) {
         return fail(RTK_ERR_INVALID, "max_ray_depth must be in [0, 16]");
     if (p->diffuse_rays < 0 || p->diffuse_rays > 32767) return fail(RTK_ERR_INVALID, "diffuse_rays must be in [0, 32767]");
     if (!valid_frame_mode(p->trace_mode)) return fail(RTK_ERR_INVALID, "unknown trace_mode");
+    if (p->sample_begin < 0 || p->sample_count < 0 || p->sample_begin >= p->spp ||
+        int64_t(p->sample_begin) + p->sample_count > p->spp)
+        return fail(RTK_ERR_INVALID, "sample_begin / sample_count must select samples inside [0, spp)");
+    if (p->sample_count == 0 && p->sample_begin != 0) return fail(RTK_ERR_INVALID, "sample_count == 0 means all samples: sample_begin must be 0");
+    g.sample_begin = p->sample_begin;
+    g.sample_end = p->sample_count == 0 ? p->spp : p->sample_begin + p->sample_count;
     g.world = p->world_size > 1 ? p->world_size : 1;
     g.rank = p->world_size > 1 ? p->rank : 0;
     if (g.rank < 0 || g.rank >= g.world) return fail(RTK_ERR_INVALID, "rank must be in [0, world_size)");
@@ -560,6 +567,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     const float fov_radians = static_cast<float>(p->fov_degrees * (3.14159265358979323846 / 180.0));
     A.tan_half_fov = std::tan(fov_radians / 2.0f);
     A.spp = p->spp; A.max_depth = p->max_ray_depth; A.diffuse_rays = p->diffuse_rays; A.seed = p->seed;
+    A.sample_begin = g.sample_begin; A.sample_end = g.sample_end;
     A.shadow_bias = p->shadow_bias; A.reflection_bias = p->reflection_bias; A.refraction_bias = p->refraction_bias;
     A.bucket = g.bucket; A.tiles_x = g.tiles_x; A.tiles_y = g.tiles_y; A.n_buckets = g.n_buckets;
     A.blocks_per_bucket_side = g.blocks_side; A.buckets_per_rank = g.buckets_per_rank;
@@ -575,7 +583,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     // reference's work (every ray traced to the end), collect_stats == 2 the work of the production path.
     A.shadow_exit = (a->knobs.shadow_exit && !a->has_refractive && p->collect_stats != 1) ? 1 : 0;
     RTK_HIP(hipMemsetAsync(a->d_counters, 0, kCounterWords * sizeof(unsigned long long), s));
-    if (g.world > 1) {
+    if (g.world > 1 && g.sample_begin == 0) {
         // buckets past the end of the frame (padding so that every rank has equal length) stay zero
         size_t nf = size_t(g.buckets_per_rank) * g.bucket * g.bucket * 3;
         RTK_HIP(hipMemsetAsync(d_out, 0, nf * sizeof(float), s));
@@ -651,7 +659,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         }
         S.nodes_sorted = S.hits_sorted = S.bin_children = S.bin_hits = 0;
         RTK_HIP(hipMemsetAsync(a->ws.ctrl, 0, dev::kCtrlWords * sizeof(uint32_t), s));
-        for (int sample = 0; sample < p->spp; ++sample) {
+        for (int sample = g.sample_begin; sample < g.sample_end; ++sample) {
             S.sample = sample;
             const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, deep_level, deep_mode, sort_from, s);
             if (es != hipSuccess) return hip_fail(es, "launch streaming pipeline");
@@ -692,7 +700,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             const uint64_t sig[4] = {(uint64_t(uint32_t(g.width)) << 32) | uint32_t(g.height),
                                      (uint64_t(uint32_t(g.rank)) << 32) | uint32_t(g.world),
                                      (uint64_t(uint32_t(p->spp)) << 32) | (uint64_t(uint32_t(p->max_ray_depth)) << 16) | uint32_t(p->diffuse_rays),
-                                     (uint64_t(uint32_t(g.bucket)) << 32) | uint32_t(p->trace_mode)};
+                                     (uint64_t(uint32_t(g.bucket)) << 32) | (uint64_t(uint32_t(g.sample_end - g.sample_begin) & 0xFFFFu) << 16) | uint32_t(p->trace_mode)};
             if (a->fb_units != units) {
                 (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
                 a->fb_cost = a->fb_order = nullptr; a->fb_bins = nullptr; a->fb_units = 0; a->fb_valid = false; a->fb_order_valid = false;
@@ -738,7 +746,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         const uint32_t h = (by + g.bucket <= g.height) ? g.bucket : g.height - by;
         pixels += uint64_t(w) * h;
     }
-    a->last_primary = pixels * uint64_t(p->spp);
+    a->last_primary = pixels * uint64_t(g.sample_end - g.sample_begin);
     return RTK_OK;
 }
 
@@ -801,12 +809,80 @@ int rtk_tiles_assemble_device(const rtk_accel *a, const rtk_render_params *p, co
     return RTK_OK;
 }
 
+// ---------------------------------------------------------------- camera rays
+
+static int camera_args(rtk_accel *a, const rtk_render_params *p, int32_t sample, dev::RenderArgs &A) {
+    FrameGeom g;
+    const int rc = frame_geom(a, p, g);
+    if (rc != RTK_OK) return rc;
+    if (sample < 0 || sample >= p->spp) return fail(RTK_ERR_INVALID, "sample must be in [0, spp)");
+    std::memset(&A, 0, sizeof(A));
+    std::memcpy(A.cam_pos, a->scene.cam_pos, sizeof(A.cam_pos));
+    std::memcpy(A.cam_mat, a->scene.cam_mat, sizeof(A.cam_mat));
+    A.width = g.width; A.height = g.height;
+    A.aspect = static_cast<float>(g.width) / static_cast<float>(g.height);
+    A.tan_half_fov = std::tan(static_cast<float>(p->fov_degrees * (3.14159265358979323846 / 180.0)) / 2.0f);   // as render_device_impl
+    A.spp = p->spp; A.seed = p->seed;
+    return RTK_OK;
+}
+
+int rtk_camera_rays_device(rtk_accel *a, const rtk_render_params *p, int32_t sample, rtk_ray *d_rays, void *stream) {
+    if (!a || !p || !d_rays) return fail(RTK_ERR_INVALID, "null accel, params or ray buffer");
+    std::lock_guard<std::mutex> lock(a->mu);
+    int rc = ensure_device(a);
+    if (rc != RTK_OK) return rc;
+    dev::RenderArgs A;
+    if ((rc = camera_args(a, p, sample, A)) != RTK_OK) return rc;
+    const hipError_t e = launch_camera_rays(A, sample, d_rays, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "launch k_camera_rays");
+    return RTK_OK;
+}
+
+int rtk_camera_rays(rtk_accel *a, const rtk_render_params *p, int32_t sample, rtk_ray *rays) {
+    if (!a || !p || !rays) return fail(RTK_ERR_INVALID, "null accel, params or ray buffer");
+    FrameGeom g;
+    int rc = frame_geom(a, p, g);
+    if (rc != RTK_OK) return rc;
+    const size_t n = size_t(g.width) * g.height;
+    rtk_ray *d = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(a->mu);
+        if ((rc = ensure_device(a)) != RTK_OK) return rc;
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&d), n * sizeof(rtk_ray)));
+    }
+    rc = rtk_camera_rays_device(a, p, sample, d, nullptr);
+    hipError_t e = hipSuccess;
+    if (rc == RTK_OK) e = hipMemcpy(rays, d, n * sizeof(rtk_ray), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (rc != RTK_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "camera ray copy");
+    return RTK_OK;
+}
+
 // ---------------------------------------------------------------- image out
 
 int rtk_format_ppm(const float *rgb, int32_t width, int32_t height, char *buf, size_t cap, size_t *n) {
     if (!rgb || !n || width <= 0 || height <= 0) return fail(RTK_ERR_INVALID, "bad image");
     try {
         const std::string s = format_ppm(rgb, width, height);
+        *n = s.size();
+        if (buf) std::memcpy(buf, s.data(), s.size() < cap ? s.size() : cap);
+        return RTK_OK;
+    } catch (const std::exception &e) { return fail(RTK_ERR_INVALID, e.what()); }
+}
+
+int rtk_frame_to_rgb8_device(const float *d_rgb, size_t n, uint8_t *d_out, void *stream) {
+    if (n > 0 && (!d_rgb || !d_out)) return fail(RTK_ERR_INVALID, "null buffer");
+    if (n > (size_t(1) << 38)) return fail(RTK_ERR_INVALID, "too many values for one launch");
+    const hipError_t e = launch_to_rgb8(d_rgb, n, d_out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return hip_fail(e, "launch k_to_rgb8");
+    return RTK_OK;
+}
+
+int rtk_format_ppm_rgb8(const uint8_t *rgb8, int32_t width, int32_t height, char *buf, size_t cap, size_t *n) {
+    if (!rgb8 || !n || width <= 0 || height <= 0) return fail(RTK_ERR_INVALID, "bad image");
+    try {
+        const std::string s = format_ppm_rgb8(rgb8, width, height);
         *n = s.size();
         if (buf) std::memcpy(buf, s.data(), s.size() < cap ? s.size() : cap);
         return RTK_OK;

@@ -219,11 +219,15 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     // ---- per-lane path state
     int state = valid ? ST_NEW_SAMPLE : ST_DONE;
     int pend = PEND_CHILD_BG;
-    int sample = 0, depth = 0, light_k = 0;
+    int sample = A.sample_begin, depth = 0, light_k = 0;
     uint32_t rkey = 0, nrays = 0;         // rkey: RNG key of the ray in flight (position in the sample's ray tree)
     bool cull = false;
     Ray ray = make_ray(black, mk(1.f, 1.f, 1.f));
     V3 pixel_sum = black, ret = black;
+    if (A.sample_begin > 0 && valid) {                                     // a later pass of a progressive frame: the running sum so far
+        const float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
+        pixel_sum = mk(o[0], o[1], o[2]);
+    }
     // hit being shaded / lit
     V3 P = black, hn = black, fn = black, din = black, ncos = black, acc = black, albedo = black;
     uint32_t hit_tri = 0, hit_mat = 0;
@@ -249,12 +253,13 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         // ---------- resolve: run each lane forward until it needs a ray traced (or is done)
         while (state != ST_TRACE && state != ST_DONE) {
             if (state == ST_NEW_SAMPLE) {                                   // render.hpp:35-69
-                if (sample == A.spp) {
+                if (sample == A.sample_end) {
                     const float inv = (float)A.spp;
                     if (writer) {
                         float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
-                        if (A.spp == 1) { o[0] = pixel_sum.x; o[1] = pixel_sum.y; o[2] = pixel_sum.z; }       // x / 1.0f == x, bit for bit
-                        else { o[0] = pixel_sum.x / inv; o[1] = pixel_sum.y / inv; o[2] = pixel_sum.z / inv; }  // render.hpp:72
+                        // the last pass divides (render.hpp:72; x / 1.0f == x, bit for bit); earlier passes leave the running sum
+                        if (A.spp == 1 || A.sample_end != A.spp) { o[0] = pixel_sum.x; o[1] = pixel_sum.y; o[2] = pixel_sum.z; }
+                        else { o[0] = pixel_sum.x / inv; o[1] = pixel_sum.y / inv; o[2] = pixel_sum.z / inv; }
                     }
                     state = ST_DONE;
                     continue;
@@ -684,6 +689,26 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs A) {
     A.rgb[i * 3 + 2] = A.gathered[src * 3 + 2];
 }
 
+// ------------------------------------------------------------------------------------------------
+// The camera rays of one sample of every pixel (render.hpp:35-62), [h][w] row-major: one thread per pixel.
+__global__ __launch_bounds__(256) void k_camera_rays(RenderArgs A, int sample, rtk_ray *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)A.width * A.height) return;
+    const uint32_t px = (uint32_t)(i % A.width), py = (uint32_t)(i / A.width);
+    const Ray r = camera_ray(A, px, py, root_key(pcg_hash(A.seed), py * A.width + px, (uint32_t)sample));
+    float *o = reinterpret_cast<float *>(out + i);
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+}
+
+// write_ppm's quantisation (io/image/ppm.hpp:17-19): uint8(255.999 * clamp(c, 0, 1)), the product in double.
+__global__ __launch_bounds__(256) void k_to_rgb8(const float *rgb, size_t n, uint8_t *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c = rgb[i];
+    const float k = (c < 0.0f) ? 0.0f : ((1.0f < c) ? 1.0f : c);           // std::clamp(c, 0.f, 1.f)
+    out[i] = (uint8_t)(255.999 * (double)k);
+}
+
 }  // namespace dev
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -853,6 +878,19 @@ hipError_t launch_twopass(const dev::RenderArgs &A, bool stats, bool forks, hipS
         if (forks) hipLaunchKernelGGL((dev::k_render<RTK_TRACE_WAVE, false, true, false, 4, true>), dim3((unsigned)tiles), dim3(256), 0, s, A);
         else hipLaunchKernelGGL((dev::k_render<RTK_TRACE_WAVE, false, false, false, 4, true>), dim3((unsigned)tiles), dim3(256), 0, s, A);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_camera_rays(const dev::RenderArgs &A, int sample, rtk_ray *d_rays, hipStream_t s) {
+    const size_t n = (size_t)A.width * A.height;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(dev::k_camera_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, sample, d_rays);
+    return hipGetLastError();
+}
+
+hipError_t launch_to_rgb8(const float *d_rgb, size_t n, uint8_t *d_out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(dev::k_to_rgb8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_rgb, n, d_out);
     return hipGetLastError();
 }
 

@@ -45,6 +45,7 @@ struct RenderArgs {
     float aspect;
     float tan_half_fov;               // tanf(float(radians) / 2.0f), render.hpp:55-57
     int spp, max_depth, diffuse_rays;
+    int sample_begin, sample_end;     // this pass renders samples [sample_begin, sample_end) of every pixel (progressive accumulation)
     uint32_t seed;
     float shadow_bias, reflection_bias, refraction_bias;
     // bucket sharding
@@ -93,5 +94,7 @@ hipError_t launch_order_by_cost(const uint32_t *cost, uint8_t *bins /* [n] scrat
                                 uint32_t n, uint32_t light_below, hipStream_t s);
 hipError_t launch_twopass(const dev::RenderArgs &A, bool stats, bool forks, hipStream_t s);
 hipError_t launch_assemble(const dev::AssembleArgs &A, hipStream_t s);
+hipError_t launch_camera_rays(const dev::RenderArgs &A, int sample, rtk_ray *d_rays, hipStream_t s);
+hipError_t launch_to_rgb8(const float *d_rgb, size_t n, uint8_t *d_out, hipStream_t s);
 
 }  // namespace rtk

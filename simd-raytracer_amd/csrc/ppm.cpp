@@ -7,6 +7,23 @@
 
 namespace rtk {
 
+// the same text from already quantised channels (rtk_frame_to_rgb8_device)
+std::string format_ppm_rgb8(const uint8_t *rgb8, int width, int height) {
+    std::string out;
+    out.reserve(size_t(width) * size_t(height) * 12 + 32);
+    char tmp[48];
+    out.append(tmp, size_t(std::snprintf(tmp, sizeof(tmp), "P3\n%d %d\n255\n", width, height)));
+    for (int y = 0; y < height; ++y) {
+        const uint8_t *row = rgb8 + size_t(y) * size_t(width) * 3;
+        for (int x = 0; x < width; ++x) {
+            const int n = std::snprintf(tmp, sizeof(tmp), "%u %u %u\t", unsigned(row[x * 3]), unsigned(row[x * 3 + 1]), unsigned(row[x * 3 + 2]));
+            out.append(tmp, size_t(n));
+        }
+        out.push_back('\n');
+    }
+    return out;
+}
+
 std::string format_ppm(const float *rgb, int width, int height) {
     std::string out;
     out.reserve(size_t(width) * size_t(height) * 12 + 32);

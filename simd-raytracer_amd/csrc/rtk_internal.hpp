@@ -140,6 +140,7 @@ int scene_from_crtscene(const char *path, rtk_scene &out, std::string &err);
 int build_tree(const rtk_scene &scene, int max_depth, int max_leaf, HostTree &out, std::string &err);
 // ppm.cpp
 std::string format_ppm(const float *rgb, int width, int height);
+std::string format_ppm_rgb8(const uint8_t *rgb8, int width, int height);
 
 void set_error(const std::string &msg);
 

@@ -93,16 +93,22 @@ __device__ __forceinline__ void level_range(const uint32_t *count_words, const u
 
 // final_color += colour ; after the last sample: pixels[y][x] = final_color / spp   (render.hpp:66-74)
 __device__ __forceinline__ void emit_pixel(const StreamArgs &S, const uint32_t pix, const V3 ret) {
+    // The running sum of a pixel lives in ws.sumbuf between the samples of one pass and in the output buffer between the
+    // passes of a progressive frame (rtk_render_params.sample_begin); the sum stays in sample order either way.
     V3 sum;
     if (S.sample == 0) sum = mk(0.0f + ret.x, 0.0f + ret.y, 0.0f + ret.z);
     else {
-        const float *sb = S.ws.sumbuf + (size_t)pix * 3;
+        const float *sb = (S.sample == S.r.sample_begin ? S.r.out : S.ws.sumbuf) + (size_t)pix * 3;
         sum = mk(sb[0] + ret.x, sb[1] + ret.y, sb[2] + ret.z);
     }
-    if (S.sample == S.r.spp - 1) {
-        const float n = (float)S.r.spp;
+    if (S.sample == S.r.sample_end - 1) {
         float *o = S.r.out + (size_t)pix * 3;
-        o[0] = sum.x / n; o[1] = sum.y / n; o[2] = sum.z / n;
+        if (S.r.sample_end == S.r.spp) {
+            const float n = (float)S.r.spp;
+            o[0] = sum.x / n; o[1] = sum.y / n; o[2] = sum.z / n;
+        } else {
+            o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+        }
     } else {
         float *sb = S.ws.sumbuf + (size_t)pix * 3;
         sb[0] = sum.x; sb[1] = sum.y; sb[2] = sum.z;

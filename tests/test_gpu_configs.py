@@ -1,0 +1,155 @@
+"""GPU parity on the BASELINE configs that round 1 only ran shrunk or not at all: config 3 with its real spp and depth,
+config 4's scene at its native resolution and bucket size sharded eight ways, config 5's scene / aspect / depth / GI --
+reduced for the bit-exact comparison with the oracle and at full 3840x2160 through size-independent properties.
+Plus progressive accumulation (the spp loop cut into passes) and the device-side 8-bit output."""
+import numpy as np
+import pytest
+
+from conftest import SCENE2, SCENE5, SCENE8
+
+pytestmark = pytest.mark.gpu
+
+AUTO, LANE, WAVE, GROUP4, GROUP8, STREAM = 0, 1, 2, 3, 4, 6
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _pair(rtk, ora, path):
+    return rtk.KdTreeSimdAccel(rtk.parse_scene_file(path)), ora.Accel(ora.Scene(ora.load_crtscene(path)), ora.ACCEL_KD_SIMD)
+
+
+@pytest.mark.parametrize("mode", [GROUP4, STREAM, AUTO, GROUP8])
+def test_config5_shape_scene2_16x9_depth10_gi(rtk, ora, mode):
+    """hw15/scene2 at 16:9, max_ray_depth 10, one diffuse GI ray, several samples: the frame stack and the streaming queues
+    at their deepest (config 5 reduced to a size the oracle renders in seconds)."""
+    acc, oacc = _pair(rtk, ora, SCENE2)
+    w, h, spp = 256, 144, 3
+    ref, ocn = oacc.render(w, h, spp, 10, 1)
+    for _ in range(4 if mode == AUTO else 1):                        # AUTO times both engines on the first frames of a shape
+        rgb, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=10, diffuse_rays=1, trace_mode=mode))
+        assert cn["rays"] == ocn["rays"] and cn["primary"] == w * h * spp
+        assert np.array_equal(_bits(rgb), _bits(ref))
+
+
+@pytest.mark.parametrize("mode", [GROUP4, STREAM, AUTO])
+def test_config3_scene8_spp4_depth10(rtk, ora, mode):
+    """BASELINE config 3 with its real samples_per_pixel and max_ray_depth (reduced resolution)."""
+    acc, oacc = _pair(rtk, ora, SCENE8)
+    w, h = 320, 180
+    ref, ocn = oacc.render(w, h, 4, 10, 0)
+    for _ in range(4 if mode == AUTO else 1):
+        rgb, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h, spp=4, max_ray_depth=10, trace_mode=mode))
+        assert cn["rays"] == ocn["rays"]
+        assert np.array_equal(_bits(rgb), _bits(ref))
+
+
+def test_config4_scene2_native_1920x1920_bucket24_sharded_8_ways(rtk, ora):
+    """BASELINE config 4's frame geometry: hw15/scene2 at its own 1920x1920 with its own bucket size 24, diffuse GI, the
+    buckets dealt to 8 ranks (all rendered on this one device), gathered and assembled: the oracle's frame, bit for bit."""
+    import torch
+
+    acc, oacc = _pair(rtk, ora, SCENE2)
+    assert acc.scene.info.bucket_size == 24 and (acc.scene.info.width, acc.scene.info.height) == (1920, 1920)
+    ref, ocn = oacc.render(0, 0, 1, 5, 1)
+    world = 8
+    cfgs = [rtk.RenderConfig(spp=1, max_ray_depth=5, diffuse_rays=1, rank=r, world_size=world) for r in range(world)]
+    n = acc.output_floats(cfgs[0])
+    gathered = torch.full((world, n), float("nan"), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    rays = 0
+    for r in range(world):
+        acc.render_frame_device(cfgs[r], gathered[r].data_ptr(), stream)
+        rays += acc.last_counters()["rays"]
+    out = torch.empty((1920, 1920, 3), dtype=torch.float32, device="cuda")
+    acc.assemble_device(cfgs[0], gathered.data_ptr(), out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert rays == ocn["rays"]
+    assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref))
+
+
+def test_config5_full_resolution_properties(rtk, ora):
+    """hw15/scene2 at 3840x2160, max_ray_depth 10, diffuse GI (config 5 at one sample per pixel): the frame does not depend on
+    the engine or on the run, and it is the oracle's frame with the oracle's ray count."""
+    acc, oacc = _pair(rtk, ora, SCENE2)
+    w, h = 3840, 2160
+    cfg = dict(width=w, height=h, spp=1, max_ray_depth=10, diffuse_rays=1)
+    base, cn = acc.render_frame(rtk.RenderConfig(trace_mode=GROUP4, **cfg))
+    again, cn2 = acc.render_frame(rtk.RenderConfig(trace_mode=GROUP4, **cfg))
+    assert cn["rays"] == cn2["rays"] and np.array_equal(_bits(base), _bits(again))
+    streamed, cn3 = acc.render_frame(rtk.RenderConfig(trace_mode=STREAM, **cfg))
+    assert cn3["rays"] == cn["rays"] and np.array_equal(_bits(base), _bits(streamed))
+    ref, ocn = oacc.render(w, h, 1, 10, 1)
+    assert cn["rays"] == ocn["rays"] and cn["primary"] == w * h
+    assert np.array_equal(_bits(base), _bits(ref))
+
+
+# ---------------------------------------------------------------- progressive accumulation + 8-bit output
+
+@pytest.mark.parametrize("mode", [GROUP4, STREAM, LANE])
+def test_progressive_passes_equal_one_launch(rtk, ora, mode):
+    """render.hpp:34-72's sample loop cut into passes: 8 passes of 16 samples leave the bits of one 128-sample launch (the
+    per-pixel sum stays in sample order), and that frame is the oracle's."""
+    import torch
+
+    acc, oacc = _pair(rtk, ora, SCENE2)
+    w, h, spp = 96, 96, 128
+    whole, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=5, diffuse_rays=1, trace_mode=mode))
+    buf = torch.full((h, w, 3), float("nan"), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    rays = primary = 0
+    for k in range(8):
+        acc.render_frame_device(rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=5, diffuse_rays=1, trace_mode=mode,
+                                                 sample_begin=16 * k, sample_count=16), buf.data_ptr(), stream)
+        c = acc.last_counters()
+        rays += c["rays"]; primary += c["primary"]
+        if k == 3:                                                    # half way the buffer holds sums, not colours
+            torch.cuda.synchronize()
+            assert float(buf.max()) > float(whole.max()) * 8
+    torch.cuda.synchronize()
+    assert rays == cn["rays"] and primary == cn["primary"] == w * h * spp
+    assert np.array_equal(_bits(buf.cpu().numpy()), _bits(whole))
+    ref, ocn = oacc.render(w, h, spp, 5, 1)
+    assert ocn["rays"] == cn["rays"]
+    assert np.array_equal(_bits(whole), _bits(ref))
+
+
+def test_progressive_ragged_passes_and_bad_ranges(rtk, ora):
+    import torch
+
+    acc, _ = _pair(rtk, ora, SCENE8)
+    w, h, spp = 120, 68, 7
+    whole, _ = acc.render_frame(rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=6))
+    buf = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for begin, count in ((0, 1), (1, 4), (5, 2)):
+        acc.render_frame_device(rtk.RenderConfig(width=w, height=h, spp=spp, max_ray_depth=6, sample_begin=begin, sample_count=count),
+                                buf.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(buf.cpu().numpy()), _bits(whole))
+    for begin, count in ((7, 1), (0, 8), (-1, 2), (3, 0), (6, 2)):
+        with pytest.raises(rtk.RtkError) as e:
+            acc.render_frame_device(rtk.RenderConfig(width=w, height=h, spp=spp, sample_begin=begin, sample_count=count), buf.data_ptr(), stream)
+        assert e.value.code == rtk.RTK_ERR_INVALID
+
+
+def test_device_rgb8_gives_the_reference_ppm(rtk, ora):
+    """uint8(255.999 * clamp(c)) on the device (io/image/ppm.hpp:17-19): the P3 text made from those bytes is write_ppm's."""
+    import torch
+
+    acc, oacc = _pair(rtk, ora, SCENE5)
+    w, h = 640, 360
+    cfg = rtk.RenderConfig(width=w, height=h)
+    frame = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    acc.render_frame_device(cfg, frame.data_ptr(), stream)
+    frame[0, 0, 0] = -0.25; frame[0, 0, 1] = 1.75; frame[0, 0, 2] = float("nan")      # clamp edge cases on one pixel
+    rgb8 = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+    rtk.frame_to_rgb8_device(frame.data_ptr(), h * w * 3, rgb8.data_ptr(), stream)
+    torch.cuda.synchronize()
+    host = frame.cpu().numpy()
+    assert rtk.format_ppm_rgb8(rgb8.cpu().numpy()) == rtk.format_ppm(host)
+    ref, _ = oacc.render(w, h, 1, 5, 0)
+    ref[0, 0] = host[0, 0]
+    assert rtk.format_ppm_rgb8(rgb8.cpu().numpy()) == ora.write_ppm(ref)
