@@ -245,8 +245,9 @@ int scene_from_crtscene(const char *path, rtk_scene &out, std::string &err) {
                 if (alb->kind == JValue::String) {                    // texture_material, loader.hpp:120-125
                     dm.kind = RTK_MAT_TEXTURE;
                     dm.texture = -1;
+                    // scene.textures is a map filled with emplace (loader.hpp:249-253): of two textures with one name the FIRST stays
                     for (size_t ti = 0; ti < texture_names.size(); ++ti)
-                        if (texture_names[ti] == alb->str) dm.texture = static_cast<int32_t>(ti);
+                        if (texture_names[ti] == alb->str) { dm.texture = static_cast<int32_t>(ti); break; }
                     if (dm.texture < 0) throw Fail{RTK_ERR_INVALID, "material refers to unknown texture '" + alb->str + "'"};
                     if (texture_is_bitmap[static_cast<size_t>(dm.texture)])
                         throw Fail{RTK_ERR_UNSUPPORTED, "bitmap textures need an image decoder and are outside the accelerated path"};

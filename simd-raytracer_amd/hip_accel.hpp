@@ -13,6 +13,8 @@
 // and `render_frame` (the whole render loop device-side, replacing render/render.hpp:18-108).
 #pragma once
 
+#include <cstdio>
+#include <exception>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -138,7 +140,12 @@ struct hip_accel {
     [[nodiscard]] std::optional<hit<F>> intersect(const ray3<F> &ray) const noexcept {
         rtk_ray r{{ray.origin.x, ray.origin.y, ray.origin.z}, {ray.direction.x, ray.direction.y, ray.direction.z}};
         rtk_hit h{};
-        if (rtk_accel_intersect(accel_.get(), &r, 1, backface_culling ? 1 : 0, RTK_TRACE_AUTO, &h) != RTK_OK) return std::nullopt;
+        // intersect is noexcept in the reference (kd_tree_simd.hpp:188) and has no error channel: a device failure must not be
+        // read as "the ray missed" (a silently black frame), so it ends the program with the library's message.
+        if (rtk_accel_intersect(accel_.get(), &r, 1, backface_culling ? 1 : 0, RTK_TRACE_AUTO, &h) != RTK_OK) {
+            std::fprintf(stderr, "hip_accel::intersect: %s\n", rtk_last_error());
+            std::terminate();
+        }
         return to_hit(ray, h);
     }
 

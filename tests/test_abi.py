@@ -24,12 +24,12 @@ def test_library_exports_every_declared_symbol(rtk):
 
 
 def test_abi_version_and_struct_sizes(rtk):
-    assert rtk.abi_version() == 2
+    assert rtk.abi_version() == 3
     assert rtk.RAY_DTYPE.itemsize == 24
     assert rtk.HIT_DTYPE.itemsize == 32
     assert ctypes.sizeof(rtk.Counters) == 64
     assert ctypes.sizeof(rtk.AccelParams) == 20
-    assert ctypes.sizeof(rtk.RenderParams) == 64
+    assert ctypes.sizeof(rtk.RenderParams) == 72        # 64 + sample_begin, sample_count (ABI 3)
 
 
 def test_device_count_is_reported_without_a_gpu(rtk):
@@ -49,6 +49,20 @@ def test_compute_fails_loudly_without_a_device(rtk):
     with pytest.raises(rtk.RtkError) as e:
         acc.render_frame(rtk.RenderConfig(width=16, height=16))
     assert e.value.code == rtk.RTK_ERR_NO_DEVICE
+    with pytest.raises(rtk.RtkError) as e:
+        acc.camera_rays(rtk.RenderConfig(width=16, height=16))
+    assert e.value.code == rtk.RTK_ERR_NO_DEVICE
+
+
+def test_accel_parameters_are_validated(rtk):
+    """eps outside [FLT_MIN, 1) is refused: the reciprocal prefilter and the bundle culling assume a determinant that passes
+    `eps <= |det|` is a normal float."""
+    sc = rtk.parse_scene_file(SCENE5)
+    for eps in (0.0, -1e-6, 1e-45, 1.0, float("nan")):
+        with pytest.raises(rtk.RtkError) as e:
+            rtk.KdTreeSimdAccel(sc, eps=eps)
+        assert e.value.code == rtk.RTK_ERR_INVALID
+    rtk.KdTreeSimdAccel(sc, eps=1.17549435e-38)
 
 
 def test_product_never_imports_the_oracle():

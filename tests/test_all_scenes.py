@@ -10,9 +10,12 @@ import pytest
 from conftest import SCENES
 
 ALL = sorted(glob.glob(os.path.join(SCENES, "*", "*.crtscene")))
-NO_MATERIALS = ("hw08/scene0.crtscene", "hw15/scene0.crtscene")            # the reference's loader throws on these
+# the reference's loader throws on these (io/json/loader.hpp:246 `for (auto light : doc["lights"])`, :257 `doc["materials"]`:
+# iterating a missing key raises simdjson_error)
+NO_LIGHTS = tuple(f"hw07/scene{i}.crtscene" for i in range(5)) + ("hw09/scene0.crtscene",)
+NO_MATERIALS = tuple(f"hw08/scene{i}.crtscene" for i in range(4)) + ("hw15/scene0.crtscene",)
 BITMAP = ("hw12/scene3.crtscene", "hw12/scene4.crtscene")                  # use the JPEG texture: needs an image decoder
-LOADABLE = [p for p in ALL if not p.endswith(NO_MATERIALS + BITMAP)]
+LOADABLE = [p for p in ALL if not p.endswith(NO_LIGHTS + NO_MATERIALS + BITMAP)]
 IDS = [os.path.relpath(p, SCENES)[:-len(".crtscene")] for p in LOADABLE]
 
 
@@ -22,13 +25,14 @@ def _bits(a):
 
 
 def test_scene_set_is_complete():
-    assert len(LOADABLE) == 22 and len(ALL) == 26
+    assert len(LOADABLE) == 22 and len(ALL) == 35            # all 35 scene files of the reference
 
 
-@pytest.mark.parametrize("path", [p for p in ALL if p.endswith(NO_MATERIALS)], ids=lambda p: os.path.basename(os.path.dirname(p)) + "/" + os.path.basename(p))
+@pytest.mark.parametrize("path", [p for p in ALL if p.endswith(NO_LIGHTS + NO_MATERIALS)], ids=lambda p: os.path.basename(os.path.dirname(p)) + "/" + os.path.basename(p))
 def test_scenes_the_reference_loader_rejects_are_rejected(rtk, path):
-    """hw08/scene0 and hw15/scene0 have no "materials": the reference throws in load_mesh (loader.hpp:151 / :253);
-    the C-ABI reports RTK_ERR_PARSE instead of inventing a material."""
+    """The early homework scenes have no "lights" (hw07/*, hw09/scene0) or no "materials" (hw08/*, hw15/scene0): the
+    reference's parse_scene_file throws on the missing key (loader.hpp:246, :257); the C-ABI reports RTK_ERR_PARSE instead
+    of inventing a light or a material."""
     with pytest.raises(rtk.RtkError) as e:
         rtk.parse_scene_file(path)
     assert e.value.code == rtk.RTK_ERR_PARSE
