@@ -214,6 +214,10 @@ int rtk_render_frame(rtk_accel *accel, const rtk_render_params *p, float *rgb /*
 int rtk_render_frame_device(rtk_accel *accel, const rtk_render_params *p, float *d_out, void *hip_stream);
 /* counters of the most recent rtk_render_frame_device on this accel; synchronises the stream it ran on */
 int rtk_render_last_counters(rtk_accel *accel, rtk_counters *counters);
+/* The longest 8x8 pixel block of the most recent megakernel frame on this accel, in milliseconds (device real-time clock):
+ * the frame's critical path -- no number of compute units or GPUs makes the frame shorter than this.  0 for frames that
+ * went through the streaming pipeline or whose blocks all took less than 10 microseconds.  Synchronises the stream the frame ran on. */
+int rtk_render_last_critical_path(rtk_accel *accel, double *ms);
 /* after the all-gather: d_gathered = [world][buckets_per_rank][bucket][bucket][3] -> d_rgb [h][w][3] */
 int rtk_tiles_assemble_device(const rtk_accel *accel, const rtk_render_params *p, const float *d_gathered,
                               float *d_rgb, void *hip_stream);

@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "rtk_accel_build", "rtk_accel_tree_info", "rtk_accel_tree_dump", "rtk_accel_destroy",
     "rtk_accel_intersect", "rtk_accel_intersect_device", "rtk_accel_intersect_stats",
     "rtk_render_output_floats", "rtk_render_frame", "rtk_render_frame_device", "rtk_render_last_counters",
+    "rtk_render_last_critical_path",
     "rtk_tiles_assemble_device", "rtk_camera_rays", "rtk_camera_rays_device",
     "rtk_frame_to_rgb8_device", "rtk_format_ppm_rgb8", "rtk_write_ppm", "rtk_format_ppm",
 ]
@@ -138,6 +139,7 @@ _L.rtk_render_output_floats.argtypes = [_vp, C.POINTER(RenderParams), C.POINTER(
 _L.rtk_render_frame.argtypes = [_vp, C.POINTER(RenderParams), _vp, C.POINTER(Counters)]
 _L.rtk_render_frame_device.argtypes = [_vp, C.POINTER(RenderParams), _vp, _vp]
 _L.rtk_render_last_counters.argtypes = [_vp, C.POINTER(Counters)]
+_L.rtk_render_last_critical_path.argtypes = [_vp, C.POINTER(C.c_double)]
 _L.rtk_tiles_assemble_device.argtypes = [_vp, C.POINTER(RenderParams), _vp, _vp, _vp]
 _L.rtk_camera_rays.argtypes = [_vp, C.POINTER(RenderParams), C.c_int32, _vp]
 _L.rtk_camera_rays_device.argtypes = [_vp, C.POINTER(RenderParams), C.c_int32, _vp, _vp]
@@ -378,6 +380,12 @@ class KdTreeSimdAccel:
     def camera_rays_device(self, cfg: RenderConfig, d_rays_ptr: int, sample: int = 0, stream: int = 0) -> None:
         p = cfg.to_c()
         _check(_L.rtk_camera_rays_device(self._h, C.byref(p), sample, d_rays_ptr, stream))
+
+    def last_critical_path_ms(self) -> float:
+        """Longest 8x8 pixel block of the most recent megakernel frame (ms): the frame's critical path."""
+        ms = C.c_double(0.0)
+        _check(_L.rtk_render_last_critical_path(self._h, C.byref(ms)))
+        return ms.value
 
     def assemble_device(self, cfg: RenderConfig, d_gathered_ptr: int, d_rgb_ptr: int, stream: int = 0) -> None:
         p = cfg.to_c()

@@ -773,6 +773,19 @@ int rtk_render_last_counters(rtk_accel *a, rtk_counters *c) {
     return RTK_OK;
 }
 
+int rtk_render_last_critical_path(rtk_accel *a, double *ms) {
+    if (!a || !ms) return fail(RTK_ERR_INVALID, "null accel or ms");
+    std::lock_guard<std::mutex> lock(a->mu);
+    if (!a->on_device) return fail(RTK_ERR_INVALID, "no frame has been rendered on this accel");
+    RTK_HIP(hipSetDevice(a->device));
+    RTK_HIP(hipStreamSynchronize(a->last_stream));
+    unsigned long long shard[kRayCounterShards], ticks = 0;
+    RTK_HIP(hipMemcpy(shard, a->d_counters + kCriticalWord, sizeof(shard), hipMemcpyDeviceToHost));
+    for (unsigned long long t : shard) ticks = t > ticks ? t : ticks;
+    *ms = double(ticks) * 1.0e-5;                                        // s_memrealtime counts at 100 MHz; 0 = no block took 10 us
+    return RTK_OK;
+}
+
 int rtk_render_frame(rtk_accel *a, const rtk_render_params *p, float *rgb, rtk_counters *counters) {
     if (!a || !p || !rgb) return fail(RTK_ERR_INVALID, "null accel, params or rgb");
     if (p->world_size > 1) return fail(RTK_ERR_INVALID, "rtk_render_frame renders whole frames; use rtk_render_frame_device for sharded output");

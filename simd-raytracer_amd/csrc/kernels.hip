@@ -196,6 +196,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     __shared__ float park_lds[4][18][64];                                  // light workgroups exist for SLICES == 4 only (api.hip)
     const uint32_t park_slot = (SLICES > 1 && !light) ? 0u : (wave_in_wg & 3u);
     const unsigned long long cost_t0 = __builtin_readcyclecounter();
+    const unsigned long long real_t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, for the frame's critical path (bench.py)
     constexpr bool writer = true;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
     const uint32_t local_bucket = gwave / bpb, sub = gwave % bpb;
@@ -595,6 +596,11 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     if (A.cost_out != nullptr && lane == 0u && gwave < A.n_units) {        // what this block cost, for the next frame's order
         const unsigned long long dt = (__builtin_readcyclecounter() - cost_t0) >> 4;
         A.cost_out[gwave] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
+    }
+    {   // the longest pixel block of the frame: what the frame cannot be shorter than.  Only long blocks report, into one of 64
+        // words (a single word takes ~88 atomics per microsecond: every block reporting would serialise the frame).
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - real_t0;
+        if (lane == 0u && dt >= kCriticalMinTicks) atomicMax(A.counters + kCriticalWord + (gwave % (uint32_t)kRayCounterShards), dt);
     }
     if (SLICES > 1 && !light) group_post_exit(group_sh);
     const uint32_t total = wave_sum(nrays);

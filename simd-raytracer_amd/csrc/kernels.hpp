@@ -9,7 +9,9 @@ namespace rtk {
 
 constexpr int kMaxRayDepth = 16;                 // frame-stack capacity of the render kernel
 constexpr int kRayCounterShards = 64;              // k_render spreads its per-wave ray-count atomics over this many words
-constexpr int kCounterWords = 8 + kRayCounterShards;
+constexpr int kCriticalWord = 8 + kRayCounterShards;   // [kRayCounterShards] longest pixel block of the frame in s_memrealtime ticks (10 ns), sharded
+constexpr unsigned long long kCriticalMinTicks = 1000;   // blocks shorter than 10 us do not report (one atomic per block would serialise the frame)
+constexpr int kCounterWords = 8 + 2 * kRayCounterShards;
 constexpr int kCostBins = 64;                      // two-pass frames: log-scale cost bins for longest-first scheduling
 constexpr uint32_t kSliceMinTrisDefault = 12;    // GROUP modes: leaves below this are tested whole by every wave
 constexpr size_t kMaxNodeLdsBytes = 48 * 1024;   // node arrays up to this size are staged in LDS (1536 nodes)

@@ -17,9 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def counter_means(path, kernel_sub, stats_marker="true"):
-    """mean Counter_Value per counter over the launches of the timed (non-stats) instantiation of the kernel"""
-    sums, counts = defaultdict(float), defaultdict(int)
-    name = None
+    """mean Counter_Value per counter over the launches of the timed instantiation of the kernel: the most frequent
+    non-counting (STATS = false) instantiation -- the run also launches the kernel on a 64x64 warm-up frame (another
+    template instance) and twice in its counting build"""
+    rows = []
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
@@ -28,9 +29,19 @@ def counter_means(path, kernel_sub, stats_marker="true"):
             args = k.split("<", 1)[-1].split(",")
             if len(args) > 1 and args[1].strip() == stats_marker:      # the one-off counting launch
                 continue
-            name = k
-            sums[row["Counter_Name"]] += float(row["Counter_Value"])
-            counts[row["Counter_Name"]] += 1
+            rows.append(row)
+    if not rows:
+        return None, {}, 0
+    freq = defaultdict(int)
+    for row in rows:
+        freq[row["Kernel_Name"]] += 1
+    name = max(freq, key=freq.get)
+    sums, counts = defaultdict(float), defaultdict(int)
+    for row in rows:
+        if row["Kernel_Name"] != name:
+            continue
+        sums[row["Counter_Name"]] += float(row["Counter_Value"])
+        counts[row["Counter_Name"]] += 1
     return name, {c: sums[c] / counts[c] for c in sums}, (max(counts.values()) if counts else 0)
 
 
@@ -43,6 +54,9 @@ def main():
     stats = newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    stats_x = newest(glob.glob(os.path.join(src, "trace_extras", "*", "*_kernel_stats.csv")))
+    if stats_x:                                   # configs 3 and 4's shape (tools/time_configs.py): the streaming pipeline's kernels
+        shutil.copy(stats_x[0], os.path.join(dst, f"{tag}_extras_kernel_stats.csv"))
     merged, launches, kname = {}, 0, None
     for pass_dir in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if not os.path.isdir(pass_dir):
@@ -64,7 +78,7 @@ def main():
             "TCC_HIT_sum": hit, "TCC_MISS_sum": miss, "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
             "hbm_bytes_per_launch": merged["FETCH_SIZE"] * 1024 * 2 + merged["WRITE_SIZE"] * 1024,
             "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate runs of "
-                      "`python bench.py --no-cpu-baseline --steps 5 --warmup 2`, tools/profile_bench.sh), mean over "
+                      "`python bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2`, tools/profile_bench.sh), mean over "
                       f"{launches} launches; FETCH_SIZE*1024*2 (gfx950 half-count correction, MI355X_MICROARCH.md §HBM) "
                       f"+ WRITE_SIZE*1024; profiles/{tag}_pmc_means.csv",
         }
