@@ -60,6 +60,7 @@ struct rtk_knobs {
     uint32_t auto_min_lanes = 12;                           // RTK_AUTO_MIN_LANES
     int stream_sort_from = -1;                              // RTK_STREAM_SORT_FROM (-1 = default)
     bool stream_debug = false;                              // RTK_STREAM_DEBUG
+    int stream_lanes = 4;                                   // RTK_STREAM_LANES: samples of a frame in flight at once (1..kStreamLanes); 8 measured no faster
 
     static rtk_knobs from_env() {
         rtk_knobs k;
@@ -79,6 +80,7 @@ struct rtk_knobs {
         if (geti("RTK_AUTO_MIN_LANES", v) && v > 0 && v <= 64) k.auto_min_lanes = uint32_t(v);
         if (geti("RTK_STREAM_SORT_FROM", v)) k.stream_sort_from = int(v);
         if (geti("RTK_STREAM_DEBUG", v)) k.stream_debug = v != 0;
+        if (geti("RTK_STREAM_LANES", v) && v >= 1 && v <= rtk::dev::kStreamLanes) k.stream_lanes = int(v);
         return k;
     }
 };
@@ -104,7 +106,13 @@ struct rtk_accel {
     rtk::DevTriUv *d_tri_uv = nullptr;
     unsigned long long *d_counters = nullptr;     // 8 x u64 in rtk_counters order + kRayCounterShards ray-count shards
     // streaming-pipeline workspace (grown on demand)
+    // one per sample lane (stream.hpp kStreamLanes); `ws` = lane 0; all lanes share lane 0's sumbuf
     rtk::dev::StreamWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr, nullptr};
+    rtk::dev::StreamWs ws_lane[rtk::dev::kStreamLanes] = {};
+    int ws_lanes = 0;
+    hipStream_t lane_stream[rtk::dev::kStreamLanes] = {};
+    hipEvent_t lane_done[rtk::dev::kStreamLanes] = {};
+    hipEvent_t lane_fork = nullptr;
     size_t ws_pixels = 0, ws_lights = 0, ws_nodes = 0;
     bool ws_sum = false;
     // two-pass workspace
@@ -178,33 +186,52 @@ dev::TreeView tree_view(const rtk_accel *a) {
 
 // (Re)allocates the streaming workspace for `pixels` output pixels.  Allocation synchronises the device, so it only
 // happens when a larger frame (or more lights / multi-sample) is requested than ever before on this accel.
-int ensure_stream_ws(rtk_accel *a, size_t pixels, size_t nodes, size_t lights, bool need_sum) {
+void free_stream_ws(rtk_accel *a) {
+    (void)hipFree(a->ws.sumbuf);
+    for (int j = 0; j < dev::kStreamLanes; ++j) {
+        dev::StreamWs &w = a->ws_lane[j];
+        (void)hipFree(w.rays); (void)hipFree(w.nodes); (void)hipFree(w.hits); (void)hipFree(w.contrib); (void)hipFree(w.ctrl);
+        (void)hipFree(w.node_bins); (void)hipFree(w.hit_bins); (void)hipFree(w.node_order); (void)hipFree(w.hit_order);
+        w = dev::StreamWs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr, nullptr};
+    }
+    a->ws = a->ws_lane[0];
+    a->ws_lanes = 0; a->ws_pixels = 0; a->ws_nodes = 0; a->ws_lights = 0; a->ws_sum = false;
+}
+
+int ensure_stream_ws(rtk_accel *a, size_t pixels, size_t nodes, size_t lights, bool need_sum, int lanes) {
     if (lights == 0) lights = 1;
-    if (pixels <= a->ws_pixels && nodes <= a->ws_nodes && lights <= a->ws_lights && (!need_sum || a->ws_sum)) return RTK_OK;
+    if (lanes < 1) lanes = 1;
+    if (pixels <= a->ws_pixels && nodes <= a->ws_nodes && lights <= a->ws_lights && (!need_sum || a->ws_sum) && lanes <= a->ws_lanes) return RTK_OK;
     const size_t np = pixels > a->ws_pixels ? pixels : a->ws_pixels;
     const size_t nn = nodes > a->ws_nodes ? nodes : a->ws_nodes;
     const size_t nl = lights > a->ws_lights ? lights : a->ws_lights;
+    const int nlanes = lanes > a->ws_lanes ? lanes : a->ws_lanes;
     const bool sum = need_sum || a->ws_sum;
     if (nn > 0xFFFFFFF0ull) return fail(RTK_ERR_INVALID, "frame too large for the streaming pipeline's 32-bit node ids");
     RTK_HIP(hipDeviceSynchronize());
-    (void)hipFree(a->ws.rays); (void)hipFree(a->ws.nodes); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
-    (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
-    (void)hipFree(a->ws.node_bins); (void)hipFree(a->ws.hit_bins); (void)hipFree(a->ws.node_order); (void)hipFree(a->ws.hit_order);
-    a->ws = dev::StreamWs{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, nullptr, nullptr, nullptr};
-    a->ws_pixels = 0; a->ws_nodes = 0; a->ws_lights = 0; a->ws_sum = false;
+    free_stream_ws(a);
     const size_t nh = nn / 2 + 64;                            // every shading point belongs to a distinct node
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.rays), nn * sizeof(dev::RayRec)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.nodes), nn * sizeof(dev::NodeRes)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.hits), nh * sizeof(dev::HitRec)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.contrib), nh * nl * sizeof(float2)));
-    if (sum) RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.sumbuf), np * 3 * sizeof(float)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.ctrl), dev::kCtrlWords * sizeof(uint32_t)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.node_bins), dev::kSortBins * sizeof(uint32_t)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.hit_bins), dev::kSortBins * sizeof(uint32_t)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.node_order), nn * sizeof(uint32_t)));
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->ws.hit_order), nh * sizeof(uint32_t)));
-    a->ws.node_cap = uint32_t(nn); a->ws.hit_cap = uint32_t(nh);
-    a->ws_pixels = np; a->ws_nodes = nn; a->ws_lights = nl; a->ws_sum = sum;
+    float *sumbuf = nullptr;
+    if (sum) RTK_HIP(hipMalloc(reinterpret_cast<void **>(&sumbuf), np * 3 * sizeof(float)));
+    for (int j = 0; j < nlanes; ++j) {
+        dev::StreamWs &w = a->ws_lane[j];
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&w.rays), nn * sizeof(dev::RayRec)));
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&w.nodes), nn * sizeof(dev::NodeRes)));
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&w.hits), nh * sizeof(dev::HitRec)));
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&w.contrib), nh * nl * sizeof(float2)));
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&w.ctrl), dev::kCtrlWords * sizeof(uint32_t)));
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&w.node_bins), dev::kSortBins * sizeof(uint32_t)));
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&w.hit_bins), dev::kSortBins * sizeof(uint32_t)));
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&w.node_order), nn * sizeof(uint32_t)));
+        RTK_HIP(hipMalloc(reinterpret_cast<void **>(&w.hit_order), nh * sizeof(uint32_t)));
+        w.sumbuf = sumbuf;
+        w.node_cap = uint32_t(nn); w.hit_cap = uint32_t(nh);
+        if (j > 0 && !a->lane_stream[j]) RTK_HIP(hipStreamCreateWithFlags(&a->lane_stream[j], hipStreamNonBlocking));
+        if (!a->lane_done[j]) RTK_HIP(hipEventCreateWithFlags(&a->lane_done[j], hipEventDisableTiming));
+    }
+    if (!a->lane_fork) RTK_HIP(hipEventCreateWithFlags(&a->lane_fork, hipEventDisableTiming));
+    a->ws = a->ws_lane[0];
+    a->ws_lanes = nlanes; a->ws_pixels = np; a->ws_nodes = nn; a->ws_lights = nl; a->ws_sum = sum;
     return RTK_OK;
 }
 
@@ -460,9 +487,10 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipFree(a->d_nodes); (void)hipFree(a->d_leaves); (void)hipFree(a->d_tris); (void)hipFree(a->d_tri_ids); (void)hipFree(a->d_shade);
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
         (void)hipFree(a->d_textures); (void)hipFree(a->d_tri_uv);
-        (void)hipFree(a->ws.rays); (void)hipFree(a->ws.nodes); (void)hipFree(a->ws.hits); (void)hipFree(a->ws.contrib);
-        (void)hipFree(a->ws.sumbuf); (void)hipFree(a->ws.ctrl);
-        (void)hipFree(a->ws.node_bins); (void)hipFree(a->ws.hit_bins); (void)hipFree(a->ws.node_order); (void)hipFree(a->ws.hit_order);
+        free_stream_ws(a);
+        for (auto &st : a->lane_stream) if (st) (void)hipStreamDestroy(st);
+        for (auto &e : a->lane_done) if (e) (void)hipEventDestroy(e);
+        if (a->lane_fork) (void)hipEventDestroy(a->lane_fork);
         (void)hipFree(a->tp_prim); (void)hipFree(a->tp_bins); (void)hipFree(a->tp_bin_list); (void)hipFree(a->tp_order);
         (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
         for (auto &e : a->trial_ev) if (e) (void)hipEventDestroy(e);
@@ -640,12 +668,16 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         // children per interface), so they get more head room; an overflow is caught on the device and the frame
         // redone by the megakernel.
         const size_t factor = a->knobs.stream_node_factor > 0 ? size_t(a->knobs.stream_node_factor) : (forks ? 8 : 3);
-        rc = ensure_stream_ws(a, out_pixels, n_root * factor + 4096, a->scene.lights.size(), p->spp > 1);
+        const int n_pass = g.sample_end - g.sample_begin;
+        const int lanes = n_pass < a->knobs.stream_lanes ? n_pass : a->knobs.stream_lanes;     // samples in flight at once (stream.hpp)
+        rc = ensure_stream_ws(a, out_pixels, n_root * factor + 4096, a->scene.lights.size(), p->spp > 1, lanes);
         if (rc != RTK_OK) return rc;
         dev::StreamArgs S;
         S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root); S.auto_min_lanes = a->knobs.auto_min_lanes;
+        S.n_lanes = uint32_t(lanes);
+        for (int j = 0; j < dev::kStreamLanes; ++j) S.lane_overflow[j] = a->ws_lane[j < lanes ? j : 0].ctrl + dev::kCtrlOverflow;
         // measured on MI355X: the workgroup-cooperative wave walk beats the per-lane walk at every depth, even for the
-        // incoherent rays behind refractive surfaces (tools/sweep_stream.sh), so no level switches strategy by default
+        // incoherent rays behind refractive surfaces, so no level switches strategy by default
         const int deep_level = a->knobs.stream_deep_level, deep_mode = a->knobs.stream_deep_mode;
         // fork-free trees stay coherent; sorting them would only add launches
         const int sort_from = a->knobs.stream_sort_from >= 0 ? a->knobs.stream_sort_from : (forks ? 1 : 99);
@@ -658,12 +690,25 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             }
         }
         S.nodes_sorted = S.hits_sorted = S.bin_children = S.bin_hits = 0;
-        RTK_HIP(hipMemsetAsync(a->ws.ctrl, 0, dev::kCtrlWords * sizeof(uint32_t), s));
+        for (int j = 0; j < lanes; ++j) RTK_HIP(hipMemsetAsync(a->ws_lane[j].ctrl, 0, dev::kCtrlWords * sizeof(uint32_t), s));
+        // fork: lane 0 is the caller's stream, the other lanes wait for everything enqueued on it so far
+        if (lanes > 1) {
+            RTK_HIP(hipEventRecord(a->lane_fork, s));
+            for (int j = 1; j < lanes; ++j) RTK_HIP(hipStreamWaitEvent(a->lane_stream[j], a->lane_fork, 0));
+        }
         for (int sample = g.sample_begin; sample < g.sample_end; ++sample) {
+            const int i = sample - g.sample_begin, j = i % lanes;
             S.sample = sample;
-            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, deep_level, deep_mode, sort_from, s);
+            S.ws = a->ws_lane[j];
+            const hipStream_t ls = j == 0 ? s : a->lane_stream[j];
+            const hipEvent_t wait = (lanes > 1 && i > 0) ? a->lane_done[(i - 1) % lanes] : nullptr;
+            const hipEvent_t done = lanes > 1 ? a->lane_done[j] : nullptr;
+            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, deep_level, deep_mode, sort_from, ls, wait, done);
             if (es != hipSuccess) return hip_fail(es, "launch streaming pipeline");
         }
+        // join: the caller's stream continues behind the last sample of every lane
+        for (int j = 1; j < lanes; ++j) RTK_HIP(hipStreamWaitEvent(s, a->lane_done[j], 0));
+        S.ws = a->ws;
         // safety net: if any queue overflowed, the megakernel renders the frame again (a no-op otherwise)
         hipError_t ef = launch_stream_overflow_reset(S, s);
         if (ef != hipSuccess) return hip_fail(ef, "launch overflow reset");

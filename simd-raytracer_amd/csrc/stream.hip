@@ -488,6 +488,8 @@ __global__ __launch_bounds__(256) void k_sort_scatter_hits(StreamArgs S) {
 __global__ __launch_bounds__(256) void k_combine(StreamArgs S) {
     const RenderArgs &A = S.r;
     if (S.ws.ctrl[kCtrlOverflow] != 0u) return;                                // the megakernel redoes the frame
+    if (S.level == 0u)                                                         // pixels are only touched while no sample of the frame has overflowed
+        for (uint32_t j = 0; j < S.n_lanes; ++j) if (*S.lane_overflow[j] != 0u) return;
     uint32_t base, count;
     level_range(S.ws.ctrl + kCtrlNodeCount, S.n_root, S.level, S.ws.node_cap, base, count);
     const uint32_t n_lights = (uint32_t)A.n_lights;
@@ -536,8 +538,16 @@ __global__ __launch_bounds__(256) void k_combine(StreamArgs S) {
 }
 
 // zeroes the counters when the streamed frame overflowed (the megakernel that redoes it counts from scratch)
-__global__ void k_reset_counters_if(unsigned long long *counters, const uint32_t *flag) {
-    if (*flag != 0u && threadIdx.x < (unsigned)kCounterWords) counters[threadIdx.x] = 0ull;
+__global__ void k_reset_counters_if(unsigned long long *counters, StreamArgs S) {
+    __shared__ uint32_t any;
+    if (threadIdx.x == 0u) {
+        uint32_t f = 0u;
+        for (uint32_t j = 0; j < S.n_lanes; ++j) f |= *S.lane_overflow[j];
+        S.ws.ctrl[kCtrlOverflow] = f;                                           // lane 0's word is what the fallback launch looks at
+        any = f;
+    }
+    __syncthreads();
+    if (any != 0u && threadIdx.x < (unsigned)kCounterWords) counters[threadIdx.x] = 0ull;
 }
 
 }  // namespace dev
@@ -567,7 +577,7 @@ void launch_shadow(const dev::StreamArgs &S, bool stats, unsigned units, hipStre
 // from `deep_level` on `deep_mode` (RTK_TRACE_AUTO / _LANE / _WAVE) applies.  From depth `sort_from_level` on, the
 // level's rays and shading points are counting-sorted for coherence before they are cut into 64-ray work units.
 hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, int sort_from_level,
-                                hipStream_t s) {
+                                hipStream_t s, hipEvent_t wait_before_emit, hipEvent_t done) {
     dev::StreamArgs S = base;
     const dev::RenderArgs &A = S.r;
     if (S.n_root == 0) return hipSuccess;
@@ -615,13 +625,21 @@ hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int dee
     }
     for (int level = A.max_depth > 0 ? A.max_depth - 1 : 0; level >= 0; --level) {
         S.level = (uint32_t)level;
+        if (level == 0 && wait_before_emit != nullptr) {                    // the running pixel sums take the samples in order
+            e = hipStreamWaitEvent(s, wait_before_emit, 0);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(dev::k_combine, dim3(level == 0 ? 2048 : 1024), dim3(256), 0, s, S);
+    }
+    if (done != nullptr) {
+        e = hipEventRecord(done, s);
+        if (e != hipSuccess) return e;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_stream_overflow_reset(const dev::StreamArgs &S, hipStream_t s) {
-    hipLaunchKernelGGL(dev::k_reset_counters_if, dim3(1), dim3(128), 0, s, S.r.counters, S.ws.ctrl + dev::kCtrlOverflow);
+    hipLaunchKernelGGL(dev::k_reset_counters_if, dim3(1), dim3(256), 0, s, S.r.counters, S);
     return hipGetLastError();
 }
 

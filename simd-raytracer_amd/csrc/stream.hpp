@@ -72,9 +72,17 @@ struct StreamWs {
     uint32_t *hit_order;    // [hit_cap] hit ids of the current level in sorted order
 };
 
+// Samples of a frame are independent ray trees: up to kStreamLanes of them are in flight at once, each on its own HIP stream
+// with its own queues, so that the tail of one sample's level (a few slow work units) overlaps the other samples' work.
+// Only the last kernel of a sample (k_combine at depth 0, which adds the sample to the running pixel sums) is ordered
+// behind the previous sample's, by an event: the sums stay in sample order.
+constexpr int kStreamLanes = 8;          // upper bound; the default is 4 (api.hip rtk_knobs)
+
 struct StreamArgs {
     RenderArgs r;
     StreamWs ws;
+    const uint32_t *lane_overflow[kStreamLanes];   // the overflow words of all lanes in use (k_combine at depth 0 emits nothing if any is set)
+    uint32_t n_lanes;
     uint32_t level;
     int sample;
     uint32_t n_root;        // level-0 nodes: 64 per 8x8 pixel block of this rank
@@ -88,8 +96,11 @@ struct StreamArgs {
 
 }  // namespace dev
 
+// `wait_before_emit` (may be null): the depth-0 k_combine waits for it (the previous sample's `done`); `done` (may be null) is
+// recorded behind it.
 hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, int sort_from_level,
-                                hipStream_t s);
+                                hipStream_t s, hipEvent_t wait_before_emit, hipEvent_t done);
+// ORs the lanes' overflow words into lane 0's, then zeroes the ray counters if it is set (the megakernel that redoes the frame counts from scratch)
 hipError_t launch_stream_overflow_reset(const dev::StreamArgs &S, hipStream_t s);
 
 }  // namespace rtk
