@@ -60,6 +60,7 @@ struct rtk_knobs {
     uint32_t auto_min_lanes = 12;                           // RTK_AUTO_MIN_LANES
     int stream_sort_from = -1;                              // RTK_STREAM_SORT_FROM (-1 = default)
     bool stream_debug = false;                              // RTK_STREAM_DEBUG
+    bool stream_side = true;                                // RTK_STREAM_SIDE: k_shadow on side streams
     int stream_lanes = 4;                                   // RTK_STREAM_LANES: samples of a frame in flight at once (1..kStreamLanes); 8 measured no faster
 
     static rtk_knobs from_env() {
@@ -80,6 +81,7 @@ struct rtk_knobs {
         if (geti("RTK_AUTO_MIN_LANES", v) && v > 0 && v <= 64) k.auto_min_lanes = uint32_t(v);
         if (geti("RTK_STREAM_SORT_FROM", v)) k.stream_sort_from = int(v);
         if (geti("RTK_STREAM_DEBUG", v)) k.stream_debug = v != 0;
+        if (geti("RTK_STREAM_SIDE", v)) k.stream_side = v != 0;
         if (geti("RTK_STREAM_LANES", v) && v >= 1 && v <= rtk::dev::kStreamLanes) k.stream_lanes = int(v);
         return k;
     }
@@ -113,6 +115,7 @@ struct rtk_accel {
     hipStream_t lane_stream[rtk::dev::kStreamLanes] = {};
     hipEvent_t lane_done[rtk::dev::kStreamLanes] = {};
     hipEvent_t lane_fork = nullptr;
+    rtk::StreamSide lane_side[rtk::dev::kStreamLanes] = {};     // k_shadow side streams of every lane
     size_t ws_pixels = 0, ws_lights = 0, ws_nodes = 0;
     bool ws_sum = false;
     // two-pass workspace
@@ -228,6 +231,11 @@ int ensure_stream_ws(rtk_accel *a, size_t pixels, size_t nodes, size_t lights, b
         w.node_cap = uint32_t(nn); w.hit_cap = uint32_t(nh);
         if (j > 0 && !a->lane_stream[j]) RTK_HIP(hipStreamCreateWithFlags(&a->lane_stream[j], hipStreamNonBlocking));
         if (!a->lane_done[j]) RTK_HIP(hipEventCreateWithFlags(&a->lane_done[j], hipEventDisableTiming));
+        for (int par = 0; par < 2; ++par) {
+            if (!a->lane_side[j].stream[par]) RTK_HIP(hipStreamCreateWithFlags(&a->lane_side[j].stream[par], hipStreamNonBlocking));
+            if (!a->lane_side[j].ready[par]) RTK_HIP(hipEventCreateWithFlags(&a->lane_side[j].ready[par], hipEventDisableTiming));
+            if (!a->lane_side[j].done[par]) RTK_HIP(hipEventCreateWithFlags(&a->lane_side[j].done[par], hipEventDisableTiming));
+        }
     }
     if (!a->lane_fork) RTK_HIP(hipEventCreateWithFlags(&a->lane_fork, hipEventDisableTiming));
     a->ws = a->ws_lane[0];
@@ -491,6 +499,12 @@ void rtk_accel_destroy(rtk_accel *a) {
         for (auto &st : a->lane_stream) if (st) (void)hipStreamDestroy(st);
         for (auto &e : a->lane_done) if (e) (void)hipEventDestroy(e);
         if (a->lane_fork) (void)hipEventDestroy(a->lane_fork);
+        for (auto &sd : a->lane_side)
+            for (int par = 0; par < 2; ++par) {
+                if (sd.stream[par]) (void)hipStreamDestroy(sd.stream[par]);
+                if (sd.ready[par]) (void)hipEventDestroy(sd.ready[par]);
+                if (sd.done[par]) (void)hipEventDestroy(sd.done[par]);
+            }
         (void)hipFree(a->tp_prim); (void)hipFree(a->tp_bins); (void)hipFree(a->tp_bin_list); (void)hipFree(a->tp_order);
         (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
         for (auto &e : a->trial_ev) if (e) (void)hipEventDestroy(e);
@@ -703,7 +717,10 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             const hipStream_t ls = j == 0 ? s : a->lane_stream[j];
             const hipEvent_t wait = (lanes > 1 && i > 0) ? a->lane_done[(i - 1) % lanes] : nullptr;
             const hipEvent_t done = lanes > 1 ? a->lane_done[j] : nullptr;
-            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, deep_level, deep_mode, sort_from, ls, wait, done);
+            const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, deep_level, deep_mode, sort_from, ls, wait, done,
+                                                       // (side streams help while few samples are in flight: spp 1 16.7 -> 9.1 ms on config 3;
+                                                       // with four lanes the GPU is full already and they cost 20 %)
+                                                       (a->knobs.stream_side && lanes <= 2) ? &a->lane_side[j] : nullptr);
             if (es != hipSuccess) return hip_fail(es, "launch streaming pipeline");
         }
         // join: the caller's stream continues behind the last sample of every lane

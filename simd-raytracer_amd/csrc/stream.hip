@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
         const bool valid = hl < n_hits;
         uint32_t h = hit_base + (valid ? hl : 0u);
         if (S.hits_sorted) {
-            h = valid ? S.ws.hit_order[hl] : hit_base;
+            h = valid ? S.ws.hit_order[hit_base + hl] : hit_base;          // (each level has its own stretch of hit_order: levels overlap in time)
             h = h < S.ws.hit_cap ? h : S.ws.hit_cap - 1u;
         }
         const float4 *q = reinterpret_cast<const float4 *>(S.ws.hits + h);
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter_hits(StreamArgs S) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += stride) {
         const float4 a = *reinterpret_cast<const float4 *>(S.ws.hits + hit_base + i);
         const uint32_t slot = atomicAdd(S.ws.hit_bins + grid_cell(S, mk(a.x, a.y, a.z)), 1u);
-        if (slot < n_hits) S.ws.hit_order[slot] = hit_base + i;
+        if (slot < n_hits) S.ws.hit_order[hit_base + slot] = hit_base + i;
     }
 }
 
@@ -577,7 +577,7 @@ void launch_shadow(const dev::StreamArgs &S, bool stats, unsigned units, hipStre
 // from `deep_level` on `deep_mode` (RTK_TRACE_AUTO / _LANE / _WAVE) applies.  From depth `sort_from_level` on, the
 // level's rays and shading points are counting-sorted for coherence before they are cut into 64-ray work units.
 hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, int sort_from_level,
-                                hipStream_t s, hipEvent_t wait_before_emit, hipEvent_t done) {
+                                hipStream_t s, hipEvent_t wait_before_emit, hipEvent_t done, const StreamSide *side) {
     dev::StreamArgs S = base;
     const dev::RenderArgs &A = S.r;
     if (S.n_root == 0) return hipSuccess;
@@ -610,9 +610,19 @@ hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int dee
                 e = hipMemsetAsync(S.ws.hit_bins, 0, dev::kSortBins * sizeof(uint32_t), s);
                 if (e != hipSuccess) return e;
             }
-            if (!deep) launch_shadow<4, RTK_TRACE_WAVE>(S, stats, group_units, s);
-            else if (deep_mode == RTK_TRACE_LANE) launch_shadow<1, RTK_TRACE_LANE>(S, stats, wave_units, s);
-            else launch_shadow<1, RTK_TRACE_AUTO>(S, stats, wave_units, s);
+            // k_shadow(level) only feeds k_combine: on a side stream it overlaps the path kernels of the deeper levels (and the
+            // other side stream's k_shadow), instead of making them wait for its slowest work unit
+            hipStream_t ss = s;
+            if (side != nullptr) {
+                const int par = level & 1;
+                ss = side->stream[par];
+                e = hipEventRecord(side->ready[par], s);
+                if (e == hipSuccess) e = hipStreamWaitEvent(ss, side->ready[par], 0);
+                if (e != hipSuccess) return e;
+            }
+            if (!deep) launch_shadow<4, RTK_TRACE_WAVE>(S, stats, group_units, ss);
+            else if (deep_mode == RTK_TRACE_LANE) launch_shadow<1, RTK_TRACE_LANE>(S, stats, wave_units, ss);
+            else launch_shadow<1, RTK_TRACE_AUTO>(S, stats, wave_units, ss);
         }
         if (S.bin_children) {                                  // order the next level's rays
             dev::StreamArgs N = S;
@@ -620,6 +630,13 @@ hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int dee
             hipLaunchKernelGGL(dev::k_sort_scan, dim3(1), dim3(1024), 0, s, S.ws.node_bins);
             hipLaunchKernelGGL(dev::k_sort_scatter_nodes, dim3(1024), dim3(256), 0, s, N);
             e = hipMemsetAsync(S.ws.node_bins, 0, dev::kSortBins * sizeof(uint32_t), s);
+            if (e != hipSuccess) return e;
+        }
+    }
+    if (side != nullptr) {                                       // k_combine needs every k_shadow
+        for (int par = 0; par < 2; ++par) {
+            e = hipEventRecord(side->done[par], side->stream[par]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, side->done[par], 0);
             if (e != hipSuccess) return e;
         }
     }

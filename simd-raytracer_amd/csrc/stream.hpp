@@ -96,10 +96,16 @@ struct StreamArgs {
 
 }  // namespace dev
 
+// Two side streams per sample lane for the k_shadow kernels (even / odd depth levels), with the events that order them.
+struct StreamSide {
+    hipStream_t stream[2];
+    hipEvent_t ready[2];     // recorded on the lane's stream when a level's shading points are sorted: k_shadow may start
+    hipEvent_t done[2];      // recorded on the side stream behind its last k_shadow of the sample
+};
 // `wait_before_emit` (may be null): the depth-0 k_combine waits for it (the previous sample's `done`); `done` (may be null) is
-// recorded behind it.
+// recorded behind it.  `side` (may be null): run the k_shadow kernels there.
 hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, int sort_from_level,
-                                hipStream_t s, hipEvent_t wait_before_emit, hipEvent_t done);
+                                hipStream_t s, hipEvent_t wait_before_emit, hipEvent_t done, const StreamSide *side);
 // ORs the lanes' overflow words into lane 0's, then zeroes the ray counters if it is set (the megakernel that redoes the frame counts from scratch)
 hipError_t launch_stream_overflow_reset(const dev::StreamArgs &S, hipStream_t s);
 
