@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "rtk.h"
+#include "rtk_multi.hpp"
 
 static int die(const char *what) {
     std::fprintf(stderr, "rtk_render: %s: %s\n", what, rtk_last_error());
@@ -16,8 +17,9 @@ static int die(const char *what) {
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        std::puts("Usage: ./rtk_render FILE [--width W] [--height H] [--spp N] [--depth D] [--diffuse K] [--seed S]\n"
-                  "                         [--trace auto|lane|wave] [--no-normalize] [--frames N] [--out image.ppm]");
+        std::puts("Usage: ./rtk_render FILE [--width W] [--height H] [--spp N] [--depth D] [--diffuse K] [--seed S] [--fov DEG]\n"
+                  "                         [--trace auto|lane|wave] [--no-normalize] [--frames N] [--out image.ppm]\n"
+                  "                         [--world N]   one process per GPU, buckets dealt round-robin, RCCL all-gather of the frame");
         return 1;
     }
     rtk_render_params p{};
@@ -26,7 +28,7 @@ int main(int argc, char **argv) {
     p.trace_mode = RTK_TRACE_AUTO; p.world_size = 1;
     rtk_accel_params ap{8, 64, 1e-6f, 1, -1};
     std::string out = "image.ppm";
-    int frames = 1;
+    int frames = 1, world = 0;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&](const char *name) -> const char * {
@@ -40,6 +42,8 @@ int main(int argc, char **argv) {
         else if (a == "--diffuse") p.diffuse_rays = std::atoi(val("--diffuse"));
         else if (a == "--seed") p.seed = static_cast<uint32_t>(std::strtoul(val("--seed"), nullptr, 10));
         else if (a == "--frames") frames = std::atoi(val("--frames"));
+        else if (a == "--world") world = std::atoi(val("--world"));
+        else if (a == "--fov") p.fov_degrees = std::atof(val("--fov"));
         else if (a == "--out") out = val("--out");
         else if (a == "--no-normalize") ap.normalize_hit_normal = 0;
         else if (a == "--trace") {
@@ -47,13 +51,40 @@ int main(int argc, char **argv) {
             p.trace_mode = m == "lane" ? RTK_TRACE_LANE : (m == "wave" ? RTK_TRACE_WAVE : RTK_TRACE_AUTO);
         } else { std::fprintf(stderr, "rtk_render: unknown option %s\n", a.c_str()); return 1; }
     }
+    // --world N: the rank processes are forked here, before this process has made any GPU call
+    int rank = 0;
+    std::string id_path;
+    if (world >= 1) {
+        rank = rtk_multi_fork(world, id_path);
+        if (rank < 0) return -1 - rank;                 // the launcher: every rank has exited
+        ap.device = -1;
+    }
     rtk_scene *scene = nullptr;
     if (rtk_scene_load_crtscene(argv[1], &scene) != RTK_OK) return die("scene");
     rtk_scene_info info{};
     rtk_scene_get_info(scene, &info);
+    const int w = p.width > 0 ? p.width : info.width, h = p.height > 0 ? p.height : info.height;
+    if (world >= 1) {
+        int n_dev = 0;
+        rtk_device_count(&n_dev);                       // (counting devices does not initialise one)
+        ap.device = n_dev > 0 ? rank % n_dev : -1;
+    }
     rtk_accel *accel = nullptr;
     if (rtk_accel_build(scene, &ap, &accel) != RTK_OK) return die("accel");
     rtk_scene_destroy(scene);
+    if (world >= 1) {
+        std::vector<float> rgb;
+        double best = 0.0;
+        unsigned long long rays = 0;
+        if (rtk_multi_rank(accel, p, rank, world, id_path.c_str(), frames, rgb, best, rays) != 0) return 1;
+        if (rank == 0) {
+            std::printf("Rendering took %g seconds.\n", best);
+            std::printf("%llu rays on %d GPUs, %.1f Mrays/s (render + RCCL all-gather + assemble, frame left on the device)\n", rays, world, double(rays) / best / 1e6);
+            if (rtk_write_ppm(rgb.data(), w, h, out.c_str()) != RTK_OK) return die("write_ppm");
+        }
+        rtk_accel_destroy(accel);
+        return 0;
+    }
     size_t n = 0;
     if (rtk_render_output_floats(accel, &p, &n) != RTK_OK) return die("params");
     std::vector<float> rgb(n);
@@ -65,7 +96,6 @@ int main(int argc, char **argv) {
         const double s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
         if (s < best) best = s;
     }
-    const int w = p.width > 0 ? p.width : info.width, h = p.height > 0 ? p.height : info.height;
     std::printf("Rendering took %g seconds.\n", best);                                   // src/main.cpp:21
     std::printf("%llu rays (%llu primary), %.1f Mrays/s including the device->host copy\n",
                 (unsigned long long)c.rays, (unsigned long long)c.primary, double(c.rays) / best / 1e6);

@@ -53,3 +53,19 @@ def test_rtk_render_cli_writes_the_reference_ppm(rtk, ora, tmp_path):
     ref, cn = ora.Accel(ora.Scene(ora.load_crtscene(SCENE5)), ora.ACCEL_KD_SIMD).render(320, 180, 1, 5, 0)
     assert out.read_bytes() == ora.write_ppm(ref)
     assert f"{cn['rays']} rays" in res.stdout
+
+
+@pytest.mark.gpu
+def test_rtk_render_cli_world_path_through_rccl(rtk, ora, tmp_path):
+    """`rtk_render --world N`: the launcher forks one rank process per GPU before touching the device; a rank renders its
+    buckets, the bucket buffers go through an RCCL all-gather, the frame is assembled on the device.  A one-GPU box can only
+    run world 1 (RCCL refuses two ranks on one device), which still goes through the fork, the id exchange, communicator
+    setup, the collectives and the device-resident frame."""
+    exe = os.path.join(PKG, "rtk_render")
+    out = tmp_path / "world.ppm"
+    res = subprocess.run([exe, SCENE5, "--width", "320", "--height", "180", "--world", "1", "--frames", "3", "--fov", "75", "--out", str(out)],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    ref, cn = ora.Accel(ora.Scene(ora.load_crtscene(SCENE5)), ora.ACCEL_KD_SIMD).render(320, 180, 1, 5, 0, fov_degrees=75.0)
+    assert out.read_bytes() == ora.write_ppm(ref)
+    assert f"{cn['rays']} rays on 1 GPUs" in res.stdout
