@@ -53,7 +53,8 @@ struct rtk_knobs {
     bool auto_trials = true;                                // RTK_AUTO_TRIALS
     bool cost_feedback = true;                              // RTK_COST_FEEDBACK
     unsigned resort_every = 8;                              // RTK_COST_RESORT_EVERY
-    uint32_t light_cycles = 40000u;                         // RTK_LIGHT_BELOW_CYCLES
+    uint32_t light_cycles = 140000u;                        // RTK_LIGHT_BELOW_CYCLES
+    uint32_t order_floor_cycles = 20000u;                   // RTK_ORDER_FLOOR_CYCLES
     size_t group8_below = 9000;                             // RTK_GROUP8_BELOW_BLOCKS
     int stream_node_factor = 0;                             // RTK_STREAM_NODE_FACTOR (0 = default)
     int stream_deep_level = 99, stream_deep_mode = RTK_TRACE_AUTO;   // RTK_STREAM_DEEP_LEVEL / _MODE
@@ -74,6 +75,7 @@ struct rtk_knobs {
         if (geti("RTK_COST_FEEDBACK", v)) k.cost_feedback = v != 0;
         if (geti("RTK_COST_RESORT_EVERY", v) && v > 0) k.resort_every = unsigned(v);
         if (geti("RTK_LIGHT_BELOW_CYCLES", v) && v >= 0) k.light_cycles = uint32_t(v);
+        if (geti("RTK_ORDER_FLOOR_CYCLES", v) && v >= 0) k.order_floor_cycles = uint32_t(v);
         if (geti("RTK_GROUP8_BELOW_BLOCKS", v) && v >= 0) k.group8_below = size_t(v);
         if (geti("RTK_STREAM_NODE_FACTOR", v) && v >= 1) k.stream_node_factor = int(v);
         if (geti("RTK_STREAM_DEEP_LEVEL", v)) k.stream_deep_level = int(v);
@@ -767,7 +769,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
                 (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
                 a->fb_cost = a->fb_order = nullptr; a->fb_bins = nullptr; a->fb_units = 0; a->fb_valid = false; a->fb_order_valid = false;
                 RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_cost), units * sizeof(uint32_t)));
-                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_order), (units + 4) * sizeof(uint32_t)));   // + header
+                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_order), (2 * units + 4) * sizeof(uint32_t)));   // order, header, workgroup list
                 RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_bins), units));
                 a->fb_units = units;
             }
@@ -781,14 +783,15 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
                     // blocks that cost less than this many cycles (background, a handful of nodes) are packed four to a workgroup
                     const uint32_t light_cycles = a->knobs.light_cycles;
                     const bool group_mode = frame_mode == RTK_TRACE_GROUP4;                 // light packing: GROUP4 only
-                    const hipError_t eo = launch_order_by_cost(a->fb_cost, a->fb_bins, a->fb_order, a->fb_order + units, uint32_t(units),
-                                                               group_mode ? light_cycles >> 4 : 0u, s);
+                    const hipError_t eo = launch_order_by_cost(a->fb_cost, a->fb_bins, a->fb_order, a->fb_order + units + 4, a->fb_order + units,
+                                                               uint32_t(units), group_mode ? light_cycles >> 4 : 0u,
+                                                               a->knobs.order_floor_cycles >> 4, 4u, s);
                     if (eo != hipSuccess) return hip_fail(eo, "launch k_order_by_cost");
                     a->fb_order_valid = true;
                     a->fb_age = 0;
                 }
                 a->fb_age += 1;
-                A.order_in = a->fb_order; A.order_hdr = a->fb_order + units;
+                A.order_in = a->fb_order; A.order_hdr = a->fb_order + units; A.wg_list = a->fb_order + units + 4;
             }
             A.cost_out = a->fb_cost;
             std::memcpy(a->fb_sig, sig, sizeof(sig));

@@ -91,7 +91,11 @@ struct ShadowBurstService {
     const RenderArgs &A;
     __device__ __forceinline__ void operator()(GroupShared *sh, const uint32_t slice) const {
         const uint32_t lane = __lane_id();
-        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->first) + slice;     // this wave's light
+        // job `slice` = (light, part): with fewer lights left than waves the 64 lanes are split into 2 or 4 contiguous
+        // parts (rows of the 8x8 pixel block), each traced by its own wave -- half the lanes make a tighter bundle.
+        const uint32_t plog = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->count);         // log2(parts)
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->first) + (slice >> plog);   // this wave's light
+        const uint32_t part = slice & ((1u << plog) - 1u);
         const unsigned long long mask = sh->pass_mask;
         float contrib = 0.0f;
         bool clear = true;
@@ -109,7 +113,7 @@ struct ShadowBurstService {
             const float d0 = dot(ld, ncos);
             const float cosine = (0.0f < d0) ? d0 : 0.0f;
             contrib = (L->intensity / area) * cosine;
-            const bool q = (((mask >> lane) & 1ull) != 0ull) & (0.0f < radius);    // is_occluded's loop guard, render.hpp:114
+            const bool q = (((mask >> lane) & 1ull) != 0ull) & ((lane >> (6u - plog)) == part) & (0.0f < radius);   // is_occluded's loop guard, render.hpp:114
             const Ray ray = make_ray(P + (A.shadow_bias * ld), ld);
             Stats st = {0, 0, 0, 0, 0, 0};
             SliceCtx sx = {nullptr, 0xFFFFFFFFu, 0u, true, 0u, group_private_bundles<SLICES>(sh, slice)};
@@ -168,11 +172,13 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     if (PRIMED) {
         gwave = A.tile_order[blockIdx.x];
     } else if (SLICES > 1 && A.order_in != nullptr) {
-        const uint32_t n_single = A.order_hdr[0], n_total = A.order_hdr[1];
-        if (blockIdx.x < n_single) {
-            gwave = A.order_in[blockIdx.x];
+        const uint32_t n_wgs = A.order_hdr[0], n_total = A.order_hdr[1];
+        if (blockIdx.x >= n_wgs) return;
+        const uint32_t desc = A.wg_list[blockIdx.x];                        // k_order_by_cost: workgroups by expected duration
+        if ((desc >> 31) == 0u) {
+            gwave = desc;
         } else {
-            const uint32_t idx = n_single + (blockIdx.x - n_single) * (uint32_t)SLICES + wave_in_wg;
+            const uint32_t idx = (desc & 0x7FFFFFFFu) + wave_in_wg;
             if (idx >= n_total) return;
             gwave = A.order_in[idx];
             light = true;
@@ -246,8 +252,10 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     bool burst_done = false;                 // the trace of this iteration ran as a light burst (wave-uniform)
     uint32_t burst_base = 0u;
     unsigned long long burst_lanes = 0ull;
+    uint32_t burst_shift = 6u;               // lane >> burst_shift = the lane's part of the burst
 #ifdef RTK_DEBUG_PHASES
-    unsigned long long ph_first_trace = 0, ph_after_first = 0;
+    unsigned long long ph_first_trace = 0, ph_after_first = 0, ph_wait = 0;
+    float ph_tr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ph_kind[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #endif
 
     for (;;) {
@@ -450,14 +458,19 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         const bool in_root = kRootFirst ? enters_root(A.tree, ray, need) : need;
         // light burst (ShadowBurstService): every lane about to query a light is at the same light, and more lights follow
         bool burst = false;
-        uint32_t burst_k = 0u;
+        uint32_t burst_k = 0u, burst_plog = 0u;
         unsigned long long burst_mask = 0ull;
+        bool elsewhere = false;                  // this lane's occlusion query is answered by a helper wave (another part)
         if (SLICES > 1 && !STATS && !light && A.has_refractive == 0) {
             const bool sh_lane = need & (pend == PEND_SHADOW);
             burst_mask = __builtin_amdgcn_ballot_w64(sh_lane);
             if (burst_mask != 0ull) {
                 burst_k = (uint32_t)__builtin_amdgcn_readlane(light_k, __builtin_ctzll(burst_mask));
-                burst = (__builtin_amdgcn_ballot_w64(sh_lane & ((uint32_t)light_k != burst_k)) == 0ull) & (burst_k + 1u < (uint32_t)A.n_lights);
+                const uint32_t left = (uint32_t)A.n_lights - burst_k;
+                const uint32_t nl = left < (uint32_t)SLICES ? left : (uint32_t)SLICES;
+                burst_plog = (nl * 4u <= (uint32_t)SLICES) ? 2u : (nl * 2u <= (uint32_t)SLICES) ? 1u : 0u;
+                burst = (__builtin_amdgcn_ballot_w64(sh_lane & ((uint32_t)light_k != burst_k)) == 0ull) & (1u < (nl << burst_plog));
+                elsewhere = burst & sh_lane & ((lane >> (6u - burst_plog)) != 0u);
             }
         }
         const bool quiet = kRootFirst && !burst && !(PRIMED && wave_any(primed)) && !wave_any(in_root);
@@ -505,16 +518,26 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
             if (burst) {
                 group_sh->ray_o[lane] = make_float4(P.x, P.y, P.z, ncos.x);
                 group_sh->ray_d[lane] = make_float4(ncos.y, ncos.z, 0.f, 0.f);
-                if (lane == 0u) { group_sh->pass_mask = burst_mask; group_sh->first = burst_k; group_sh->kind = GROUP_EXTRA; }
+                if (lane == 0u) { group_sh->pass_mask = burst_mask; group_sh->first = burst_k; group_sh->count = burst_plog; group_sh->kind = GROUP_EXTRA; }
                 __syncthreads();                                            // B1: the helpers start on their lights
                 sx.min_tris = 0xFFFFFFFFu;                                  // (they are busy: the owner's own leaves stay whole)
             }
-            cand = trace<MODE, STATS, kStage, SLICES, kRootFirst>(A.tree, lds_nodes, ray, cull, in_root, st, sx, kAutoMinLanes, exit_t, cls, apex);
+            cand = trace<MODE, STATS, kStage, SLICES, kRootFirst>(A.tree, lds_nodes, ray, cull, in_root & !elsewhere, st, sx, kAutoMinLanes, exit_t, cls, apex);
+#ifdef RTK_DEBUG_PHASES
+            const unsigned long long ph_w0 = __builtin_readcyclecounter();
+#endif
             if (burst) {
                 __syncthreads();                                            // B2: their answers are in LDS
                 sx.min_tris = A.slice_min_tris;
             }
-            burst_done = burst; burst_base = burst_k; burst_lanes = burst_mask;
+#ifdef RTK_DEBUG_PHASES
+            ph_wait += __builtin_readcyclecounter() - ph_w0;
+            for (int i = 0; i < 6; ++i) if (sx.n_trace == (uint32_t)i) {
+                ph_tr[i] = (float)(__builtin_readcyclecounter() - tr0);
+                ph_kind[i] = burst ? 100.f + (float)burst_plog : (float)__popcll(__builtin_amdgcn_ballot_w64(in_root));
+            }
+#endif
+            burst_done = burst; burst_base = burst_k; burst_lanes = burst_mask; burst_shift = 6u - burst_plog;
 #ifdef RTK_DEBUG_PHASES
             sx.c_trace += __builtin_readcyclecounter() - tr0; sx.n_trace += 1u;
             if (ph_after_first == 0) ph_after_first = __builtin_readcyclecounter();
@@ -535,6 +558,9 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
             const bool hit = cand.k != kMiss;
             if (pend == PEND_SHADOW) {                                       // is_occluded, render.hpp:110-131
                 bool clear = !hit | (shadow_max_t < cand.t);
+                const bool in_burst = SLICES > 1 && burst_done && ((burst_lanes >> lane) & 1ull) != 0ull;
+                const uint32_t my_part = in_burst ? (lane >> burst_shift) : 0u;
+                if (my_part != 0u) clear = group_sh->result[my_part][lane].y != 0.0f;     // light k of the other parts: a helper's answer
                 bool again = false;
                 if (!clear && A.has_refractive) {
                     const uint32_t tri = A.tree.tri_ids[cand.k];
@@ -550,12 +576,12 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                     if (clear) acc = acc + (contrib * albedo);               // :205
                     light_k += 1;
                     state = ST_LIGHT;
-                    if (SLICES > 1 && burst_done && ((burst_lanes >> lane) & 1ull) != 0ull) {
+                    if (in_burst) {
                         // the helpers' lights, in light order: the same float sum as the sequential loop
-#pragma unroll
-                        for (int s = 1; s < SLICES; ++s) {
-                            if (burst_base + (uint32_t)s < (uint32_t)A.n_lights) {
-                                const float4 res = group_sh->result[s][lane];
+                        const uint32_t plog = 6u - burst_shift;
+                        for (uint32_t s = 1u; (s << plog) < (uint32_t)SLICES; ++s) {
+                            if (burst_base + s < (uint32_t)A.n_lights) {
+                                const float4 res = group_sh->result[(s << plog) + my_part][lane];
                                 if (res.y != 0.0f) acc = acc + (res.x * albedo);
                                 nrays += __float_as_uint(res.z);
                                 light_k += 1;
@@ -582,19 +608,22 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     if (valid && writer) {
         const unsigned long long ph_now = __builtin_readcyclecounter();
         const unsigned long long ph_rt1 = __builtin_amdgcn_s_memrealtime();
-        const float vals[20] = {(float)(ph_now - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
+        const float vals[35] = {(float)(ph_now - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
                                 (float)sx.n_small, (float)sx.t_small, (float)sx.c_small, (float)sx.n_big, (float)sx.t_big, (float)sx.c_big,
                                 (float)(ph_begin - ph_entry), (float)(ph_first_trace - ph_begin), (float)(ph_after_first - ph_first_trace),
                                 (float)(ph_now - ph_after_first), (float)sx.tally.chunks, (float)sx.tally.surv, (float)sx.tally.tris,
-                                (float)(ph_rt0 & 0xFFFFFFull), (float)(ph_rt1 & 0xFFFFFFull), (float)blockIdx.x};
+                                (float)(ph_rt0 & 0xFFFFFFull), (float)(ph_rt1 & 0xFFFFFFull), (float)blockIdx.x,
+                                (float)ph_wait, ph_tr[0], ph_tr[1], ph_tr[2], ph_tr[3], ph_tr[4], ph_tr[5],
+                                ph_kind[0], ph_kind[1], ph_kind[2], ph_kind[3], ph_kind[4], ph_kind[5], (float)sx.c_bund, (float)sx.c_list};
         float v = 0.f;
-        for (int i = 0; i < 20; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
+        for (int i = 0; i < 35; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
         float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
         o[0] = v; o[1] = 0.f; o[2] = 0.f;
     }
 #endif
     if (A.cost_out != nullptr && lane == 0u && gwave < A.n_units) {        // what this block cost, for the next frame's order
-        const unsigned long long dt = (__builtin_readcyclecounter() - cost_t0) >> 4;
+        // (a block that ran alone on one wave of a packed workgroup took about twice as long as it would with helpers)
+        const unsigned long long dt = (__builtin_readcyclecounter() - cost_t0) >> (light ? 5 : 4);
         A.cost_out[gwave] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
     }
     {   // the longest pixel block of the frame: what the frame cannot be shorter than.  Only long blocks report, into one of 64
@@ -793,13 +822,19 @@ __device__ __forceinline__ uint32_t cost_bin(uint32_t c) {                 // 8 
     const uint32_t m = e >= 3u ? (c >> (e - 3u)) & 7u : (c << (3u - e)) & 7u;
     return e * 8u + m;                                                     // 0..255
 }
-__global__ __launch_bounds__(1024) void k_order_by_cost(const uint32_t *cost, uint8_t *bins, uint32_t *order, uint32_t *hdr, uint32_t n,
-                                                        uint32_t light_below) {
+__global__ __launch_bounds__(1024) void k_order_by_cost(const uint32_t *cost, uint8_t *bins, uint32_t *order, uint32_t *wg_list,
+                                                        uint32_t *hdr, uint32_t n, uint32_t light_below, uint32_t floor_below,
+                                                        uint32_t pack) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t start[256];
-    const uint32_t light_bin = light_below > 0u ? cost_bin(light_below) : 0u;  // bins below it are "light"
+    __shared__ uint32_t wg_hist[2][256], wg_base[2][256];
+    __shared__ uint32_t n_single_sh;
+    const uint32_t light_bin = light_below > 0u ? cost_bin(light_below) : 0u;  // blocks in bins below it are packed `pack` to a workgroup
+    // ... and of those, the ones below `floor_bin` need no order among themselves (background, a handful of nodes)
+    const uint32_t floor_raw = floor_below > 0u ? cost_bin(floor_below) : 0u;
+    const uint32_t floor_bin = floor_raw < light_bin ? floor_raw : light_bin;
     constexpr uint32_t kBatch = 8;                                          // loads in flight per thread: the kernel is one workgroup,
-    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) hist[i] = 0u; // so memory latency, not bandwidth, is what it waits for
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) { hist[i] = 0u; wg_hist[0][i] = 0u; wg_hist[1][i] = 0u; }   // so memory latency, not bandwidth, is what it waits for
     __syncthreads();
     // the bin of every block is computed once and kept: `order` is a permutation even if cost[] changes under us
     for (uint32_t base = 0; base < n; base += blockDim.x * kBatch) {
@@ -814,7 +849,7 @@ __global__ __launch_bounds__(1024) void k_order_by_cost(const uint32_t *cost, ui
             const uint32_t i = base + k * blockDim.x + threadIdx.x;
             // most blocks of a frame are cheap and need no order among themselves: they all go to bin 0, counted once per wave
             uint32_t b = i < n ? cost_bin(c[k]) : 0u;
-            if (b < light_bin) b = 0u;
+            if (b < floor_bin) b = 0u;
             if (i < n) bins[i] = (uint8_t)b;
             const unsigned long long cheap = __builtin_amdgcn_ballot_w64(i < n && b == 0u);
             if (i < n && b != 0u) atomicAdd(&hist[b], 1u);
@@ -824,8 +859,12 @@ __global__ __launch_bounds__(1024) void k_order_by_cost(const uint32_t *cost, ui
     __syncthreads();
     if (threadIdx.x == 0u) {
         uint32_t acc = 0u;
-        for (int b = 255; b >= 0; --b) { start[b] = acc; acc += hist[b]; }
-        hdr[0] = light_bin > 0u ? start[0] : n;                             // order[0, n_single): one workgroup each; the rest packed
+        uint32_t singles = 0u;
+        for (int b = 255; b >= 0; --b) {
+            start[b] = acc; acc += hist[b];
+            if (light_bin == 0u || (uint32_t)b >= light_bin) singles = acc;
+        }
+        n_single_sh = light_bin > 0u ? singles : n;                          // order[0, n_single): one workgroup each; the rest packed
         hdr[1] = n;
     }
     __syncthreads();
@@ -856,13 +895,49 @@ __global__ __launch_bounds__(1024) void k_order_by_cost(const uint32_t *cost, ui
             if (i < n) order[pos[k]] = i;
         }
     }
+    // The launch order of the WORKGROUPS: by how long each will run.  A packed workgroup runs its blocks one wave each, with
+    // no helpers: it takes about twice as long as its most expensive block would take alone (8 bins = one octave), and
+    // has to start as early as the single-block workgroups of that duration -- started behind all of them it is the
+    // frame's tail.  wg_list[w] = block id, or 0x80000000 | index into order[] of the first of `pack` blocks.
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t n_single = n_single_sh;
+    const uint32_t n_packed = (n - n_single + pack - 1u) / pack;
+    const uint32_t n_wgs = n_single + n_packed;
+    for (uint32_t w = threadIdx.x; w < n_wgs; w += blockDim.x) {
+        const bool packed = w >= n_single;
+        const uint32_t at = packed ? n_single + (w - n_single) * pack : w;
+        uint32_t key = (uint32_t)bins[order[at]];
+        if (packed && key != 0u) key = key + 8u < 255u ? key + 8u : 255u;
+        atomicAdd(&wg_hist[packed ? 1 : 0][key], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t acc = 0u;
+        for (int b = 255; b >= 0; --b) {
+            wg_base[0][b] = acc; acc += wg_hist[0][b];
+            wg_base[1][b] = acc; acc += wg_hist[1][b];
+        }
+        hdr[0] = n_wgs;
+    }
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < n_wgs; w += blockDim.x) {
+        const bool packed = w >= n_single;
+        const uint32_t at = packed ? n_single + (w - n_single) * pack : w;
+        const uint32_t blk = order[at];
+        uint32_t key = (uint32_t)bins[blk];
+        if (packed && key != 0u) key = key + 8u < 255u ? key + 8u : 255u;
+        const uint32_t pos = atomicAdd(&wg_base[packed ? 1 : 0][key], 1u);
+        wg_list[pos] = packed ? (0x80000000u | at) : blk;
+    }
 }
 }  // namespace dev
 
-hipError_t launch_order_by_cost(const uint32_t *cost, uint8_t *bins, uint32_t *order, uint32_t *hdr, uint32_t n,
-                                uint32_t light_below, hipStream_t s) {
+hipError_t launch_order_by_cost(const uint32_t *cost, uint8_t *bins, uint32_t *order, uint32_t *wg_list, uint32_t *hdr, uint32_t n,
+                                uint32_t light_below, uint32_t floor_below, uint32_t pack, hipStream_t s) {
     if (n == 0u) return hipSuccess;
-    hipLaunchKernelGGL(dev::k_order_by_cost, dim3(1), dim3(1024), 0, s, cost, bins, order, hdr, n, light_below);
+    if (pack == 0u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dev::k_order_by_cost, dim3(1), dim3(1024), 0, s, cost, bins, order, wg_list, hdr, n, light_below, floor_below, pack);
     return hipGetLastError();
 }
 

@@ -71,7 +71,8 @@ struct RenderArgs {
     uint32_t n_units;                 // pixel blocks (8x8) of this rank = buckets_per_rank * blocks_per_bucket_side^2
     uint32_t *cost_out;               // [n_units] or null
     const uint32_t *order_in;         // permutation of the pixel blocks, or null = natural order
-    const uint32_t *order_hdr;        // {n_single, n}: see launch_order_by_cost
+    const uint32_t *order_hdr;        // {n_workgroups, n}: see launch_order_by_cost
+    const uint32_t *wg_list;          // [n_workgroups] a block id, or 0x80000000 | index into order_in of the first block of a packed workgroup
     int shadow_exit;                  // occlusion queries may stop at the first answering hit (no transmissive material; trace())
 
     __device__ __forceinline__ size_t out_index(uint32_t local_bucket, uint32_t lx, uint32_t ly, uint32_t px,
@@ -90,10 +91,13 @@ struct AssembleArgs {
 
 hipError_t launch_intersect(const dev::IntersectArgs &A, int mode, bool stats, hipStream_t s);
 hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool forks, hipStream_t s);
-// order[0..n) = the pixel blocks sorted by cost[], most expensive first (one workgroup, counting sort over 256 log-scale bins)
-// hdr[0] = n_single: blocks costlier than light_below (units of 16 cycles), one workgroup each (the rest are packed); hdr[1] = n
-hipError_t launch_order_by_cost(const uint32_t *cost, uint8_t *bins /* [n] scratch */, uint32_t *order, uint32_t *hdr /* [2] */,
-                                uint32_t n, uint32_t light_below, hipStream_t s);
+// order[0..n) = the pixel blocks sorted by cost[], most expensive first (one workgroup, counting sort over 256 log-scale bins;
+// blocks cheaper than floor_below are not ordered among themselves).  Blocks costlier than light_below (units of 16 cycles;
+// 0 = all) get a workgroup each, the rest are packed `pack` to a workgroup; wg_list[0..hdr[0]) = the workgroups by expected
+// duration, longest first (see RenderArgs::wg_list); hdr[1] = n
+hipError_t launch_order_by_cost(const uint32_t *cost, uint8_t *bins /* [n] scratch */, uint32_t *order, uint32_t *wg_list /* [n] */,
+                                uint32_t *hdr /* [2] */, uint32_t n, uint32_t light_below, uint32_t floor_below, uint32_t pack,
+                                hipStream_t s);
 hipError_t launch_twopass(const dev::RenderArgs &A, bool stats, bool forks, hipStream_t s);
 hipError_t launch_assemble(const dev::AssembleArgs &A, hipStream_t s);
 hipError_t launch_camera_rays(const dev::RenderArgs &A, int sample, rtk_ray *d_rays, hipStream_t s);

@@ -307,34 +307,72 @@ struct BundleSet {       // wave-uniform handle of the current trace's bundles
 };
 
 // Wave-wide min / max through DPP (quad_perm, row_shr within rows of 16, then row_bcast across rows; the classic gfx9
-// reduction): the full result ends up in lane 63.  All 64 lanes must be active.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_move(const float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
+// reduction): the full result ends up in lane 63.  All 64 lanes must be active.  Written as v_min/v_max with the DPP move
+// folded in (from the builtins the compiler makes v_mov + s_nop + v_mov_dpp + canonicalise + v_max: five slots per step).
 template <bool MAX>
 __device__ __forceinline__ float wave_minmax(float v) {
-#define RTK_RED_STEP(CTRL, ROWS) { const float o = dpp_move<CTRL, ROWS>(v); v = MAX ? __builtin_fmaxf(v, o) : __builtin_fminf(v, o); }
-    RTK_RED_STEP(0xB1, 0xF)     // quad_perm [1,0,3,2]
-    RTK_RED_STEP(0x4E, 0xF)     // quad_perm [2,3,0,1]
-    RTK_RED_STEP(0x114, 0xF)    // row_shr:4
-    RTK_RED_STEP(0x118, 0xF)    // row_shr:8   -> lane 15 of every row holds the row's result
-    RTK_RED_STEP(0x142, 0xA)    // row_bcast:15 -> lanes 31 and 63 hold two rows
-    RTK_RED_STEP(0x143, 0xC)    // row_bcast:31 -> lane 63 holds all four
-#undef RTK_RED_STEP
+    // one chain: every step reads what the previous one wrote, two wait states apart (s_nop 1)
+    if (MAX)
+        asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" : "+v"(v));
+    else
+        asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Six minima and six maxima at once, each instruction a v_min/v_max with the DPP move folded in (the compiler emits
+// v_mov_b32_dpp + s_nop + v_min for every step of wave_minmax: three issue slots where one will do).  The twelve chains are
+// interleaved, so a register written by one instruction is read eleven instructions later: no DPP hazard inside the block;
+// the s_nop in front covers a VALU write of an input just before it.  Lanes without a DPP source keep their value
+// (bound_ctrl off), like min(v, v).  Results in lane 63.
+#define RTK_DPP6(OP, CTRL) \
+    OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\t" OP " %2, %2, %2 " CTRL "\n\t" \
+    OP " %3, %3, %3 " CTRL "\n\t" OP " %4, %4, %4 " CTRL "\n\t" OP " %5, %5, %5 " CTRL "\n\t"
+#define RTK_DPP6B(OP, CTRL) \
+    OP " %6, %6, %6 " CTRL "\n\t" OP " %7, %7, %7 " CTRL "\n\t" OP " %8, %8, %8 " CTRL "\n\t" \
+    OP " %9, %9, %9 " CTRL "\n\t" OP " %10, %10, %10 " CTRL "\n\t" OP " %11, %11, %11 " CTRL "\n\t"
+#define RTK_DPP_STEP12(CTRL) RTK_DPP6("v_min_f32_dpp", CTRL) RTK_DPP6B("v_max_f32_dpp", CTRL)
+#define RTK_DPP_STEP6(CTRL) \
+    "v_min_f32_dpp %0, %0, %0 " CTRL "\n\t" "v_min_f32_dpp %1, %1, %1 " CTRL "\n\t" "v_min_f32_dpp %2, %2, %2 " CTRL "\n\t" \
+    "v_max_f32_dpp %3, %3, %3 " CTRL "\n\t" "v_max_f32_dpp %4, %4, %4 " CTRL "\n\t" "v_max_f32_dpp %5, %5, %5 " CTRL "\n\t"
+#define RTK_DPP_ALL(STEP) \
+    "s_nop 1\n\t" \
+    STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") \
+    STEP("row_shr:4 row_mask:0xf bank_mask:0xf") STEP("row_shr:8 row_mask:0xf bank_mask:0xf") \
+    STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+__device__ __forceinline__ float lane63(const float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+// mins of a0..a5 -> a0..a5, maxes of b0..b5 -> b0..b5 (wave-uniform on return).  All 64 lanes must be active.
+__device__ __forceinline__ void wave_min6_max6(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5, float &b0, float &b1,
+                                               float &b2, float &b3, float &b4, float &b5) {
+    asm volatile(RTK_DPP_ALL(RTK_DPP_STEP12)
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5));
+    a0 = lane63(a0); a1 = lane63(a1); a2 = lane63(a2); a3 = lane63(a3); a4 = lane63(a4); a5 = lane63(a5);
+    b0 = lane63(b0); b1 = lane63(b1); b2 = lane63(b2); b3 = lane63(b3); b4 = lane63(b4); b5 = lane63(b5);
+}
+// mins of a0..a2, maxes of b0..b2
+__device__ __forceinline__ void wave_min3_max3(float &a0, float &a1, float &a2, float &b0, float &b1, float &b2) {
+    asm volatile(RTK_DPP_ALL(RTK_DPP_STEP6) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2));
+    a0 = lane63(a0); a1 = lane63(a1); a2 = lane63(a2); b0 = lane63(b0); b1 = lane63(b1); b2 = lane63(b2);
 }
 
 // bounds of the rays of the lanes with `in`
 __device__ __forceinline__ Bundle make_bundle(const Ray &r, const bool cull, const bool in) {
     const float inf = __builtin_inff();
     Bundle B;
-    B.olx = wave_minmax<false>(in ? r.o.x : inf);  B.ohx = wave_minmax<true>(in ? r.o.x : -inf);
-    B.oly = wave_minmax<false>(in ? r.o.y : inf);  B.ohy = wave_minmax<true>(in ? r.o.y : -inf);
-    B.olz = wave_minmax<false>(in ? r.o.z : inf);  B.ohz = wave_minmax<true>(in ? r.o.z : -inf);
-    B.dlx = wave_minmax<false>(in ? r.d.x : inf);  B.dhx = wave_minmax<true>(in ? r.d.x : -inf);
-    B.dly = wave_minmax<false>(in ? r.d.y : inf);  B.dhy = wave_minmax<true>(in ? r.d.y : -inf);
-    B.dlz = wave_minmax<false>(in ? r.d.z : inf);  B.dhz = wave_minmax<true>(in ? r.d.z : -inf);
+    B.olx = in ? r.o.x : inf; B.oly = in ? r.o.y : inf; B.olz = in ? r.o.z : inf;
+    B.dlx = in ? r.d.x : inf; B.dly = in ? r.d.y : inf; B.dlz = in ? r.d.z : inf;
+    B.ohx = in ? r.o.x : -inf; B.ohy = in ? r.o.y : -inf; B.ohz = in ? r.o.z : -inf;
+    B.dhx = in ? r.d.x : -inf; B.dhy = in ? r.d.y : -inf; B.dhz = in ? r.d.z : -inf;
+    wave_min6_max6(B.olx, B.oly, B.olz, B.dlx, B.dly, B.dlz, B.ohx, B.ohy, B.ohz, B.dhx, B.dhy, B.dhz);
     // a NaN component is invisible to min/max: any ray that is not finite and small switches the culling off
     const float L = kBundleLimit;
     const bool lane_ok = (__builtin_fabsf(r.o.x) <= L) & (__builtin_fabsf(r.o.y) <= L) & (__builtin_fabsf(r.o.z) <= L) &
@@ -342,6 +380,21 @@ __device__ __forceinline__ Bundle make_bundle(const Ray &r, const bool cull, con
     const bool ok = __builtin_amdgcn_ballot_w64(in & !lane_ok) == 0ull;
     B.flags = (ok ? BUNDLE_OK : 0u) | ((__builtin_amdgcn_ballot_w64(in & !cull) == 0ull) ? BUNDLE_ALL_CULL : 0u);
     return B;
+}
+
+// The direction box of the lanes with `in`, reduced to what a split needs: its widest axis, the half width and the middle.
+struct DirSpread { float widest, mid; uint32_t axis; };
+__device__ __forceinline__ DirSpread dir_spread(const Ray &r, const bool in) {
+    const float inf = __builtin_inff();
+    float lx = in ? r.d.x : inf, ly = in ? r.d.y : inf, lz = in ? r.d.z : inf;
+    float hx = in ? r.d.x : -inf, hy = in ? r.d.y : -inf, hz = in ? r.d.z : -inf;
+    wave_min3_max3(lx, ly, lz, hx, hy, hz);
+    DirSpread S;
+    S.widest = (hx - lx) * 0.5f; S.mid = (lx + hx) * 0.5f; S.axis = 0u;
+    const float wy = (hy - ly) * 0.5f, wz = (hz - lz) * 0.5f;
+    if (S.widest < wy) { S.widest = wy; S.axis = 1u; S.mid = (ly + hy) * 0.5f; }
+    if (S.widest < wz) { S.widest = wz; S.axis = 2u; S.mid = (lz + hz) * 0.5f; }
+    return S;                                            // (NaN directions: the comparisons fail, nothing is split)
 }
 
 // Pencil bundles.  Camera rays leave one point; shadow rays END in one (the light): the LINES of such a bundle pass through
@@ -767,7 +820,7 @@ struct SliceCtx {
                          // a wave-private area otherwise; nullptr = no bundle culling / leaf-list traversal
 #ifdef RTK_DEBUG_PHASES
     // diagnostic (tools/phase_times.py): cycles and counts of the owner's walk by phase
-    unsigned long long c_small = 0, c_big = 0, c_trace = 0;
+    unsigned long long c_small = 0, c_big = 0, c_trace = 0, c_bund = 0, c_list = 0;
     uint32_t n_steps = 0, n_small = 0, n_big = 0, t_small = 0, t_big = 0, n_trace = 0;
     CullTally tally = {0u, 0u, 0u};   // owner's own chunks / survivors / triangles seen by the bundle culling
 #endif
@@ -924,6 +977,9 @@ __device__ __forceinline__ void trace_list(const TreeView &T, const Ray &r, cons
     bool live = active;                                                    // lanes still looking for their closest hit
     uint32_t bundled = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active));   // live lanes when the bundles were last made
     for (uint32_t base = 0; base < T.n_leaves; base += 64u) {
+#ifdef RTK_DEBUG_PHASES
+        const unsigned long long pl0 = __builtin_readcyclecounter();
+#endif
         const bool have = base + lane < T.n_leaves;
         const float4 *lp = reinterpret_cast<const float4 *>(T.leaves + (have ? base + lane : 0u));
         const float4 q0 = lp[0], q1 = lp[1];
@@ -938,6 +994,7 @@ __device__ __forceinline__ void trace_list(const TreeView &T, const Ray &r, cons
         unsigned long long cm = __builtin_amdgcn_ballot_w64(have & cand);
 #ifdef RTK_DEBUG_PHASES
         sx.n_steps += (uint32_t)__popcll(cm);
+        sx.c_list += __builtin_readcyclecounter() - pl0;
 #endif
         while (cm != 0ull) {
             const int j = __builtin_ctzll(cm);
@@ -973,7 +1030,13 @@ __device__ __forceinline__ void trace_list(const TreeView &T, const Ray &r, cons
             // occlusion queries thin out as they are answered: once half of the rays the bundles were made for are gone, bundles
             // of the remaining ones are tighter (the candidate leaves found with the old bundles stay a valid superset)
             if (n_live * 2u <= bundled) {
+#ifdef RTK_DEBUG_PHASES
+                const unsigned long long pb0 = __builtin_readcyclecounter();
+#endif
                 BS.n = make_bundles(r, cull, live, cls, apex, sx.bundle_lds, cidx);
+#ifdef RTK_DEBUG_PHASES
+                sx.c_bund += __builtin_readcyclecounter() - pb0;
+#endif
                 bundled = n_live;
                 sx.rays_dirty = true;                                       // helpers re-read the bundles and the lanes' bundle indices
             }
@@ -1086,7 +1149,13 @@ __device__ __forceinline__ Cand trace(const TreeView &T, const DevNode *lds_node
             if (wave_any(in)) {
                 BundleSet BS = {sx.bundle_lds, 0u};
                 uint32_t cidx = 0u;
+#ifdef RTK_DEBUG_PHASES
+                const unsigned long long pb0 = __builtin_readcyclecounter();
+#endif
                 if (T.bundle_cull != 0 && sx.bundle_lds != nullptr) BS.n = make_bundles(r, cull, in, cls, apex, sx.bundle_lds, cidx);
+#ifdef RTK_DEBUG_PHASES
+                sx.c_bund += __builtin_readcyclecounter() - pb0;
+#endif
                 if (!STATS && BS.n != 0u && T.n_leaves <= kListMaxLeaves) trace_list<SLICES>(T, r, cull, in, best, sx, exit_t, cidx, BS, cls, apex);
                 else (void)trace_wave<STATS, SLICES>(T, r, cull, in, best, st, 1u, sx, exit_t, cidx, BS);
             }
