@@ -100,6 +100,9 @@ struct ShadowBurstService {
         float contrib = 0.0f;
         bool clear = true;
         uint32_t n = 0u;
+#ifdef RTK_DEBUG_PHASES
+        float dbg_w = 0.0f;
+#endif
         if (k < (uint32_t)A.n_lights) {
             const float PI_F = 3.14159265358979323846f;
             const float4 a = sh->ray_o[lane], b = sh->ray_d[lane];
@@ -118,11 +121,25 @@ struct ShadowBurstService {
             Stats st = {0, 0, 0, 0, 0, 0};
             SliceCtx sx = {nullptr, 0xFFFFFFFFu, 0u, true, 0u, group_private_bundles<SLICES>(sh, slice)};
             const float exit_t = A.shadow_exit ? radius : -1.0f;
+#ifdef RTK_DEBUG_PHASES
+            const unsigned long long j0 = __builtin_readcyclecounter();
+#endif
             const Cand c = trace<RTK_TRACE_WAVE, false, false, 1>(A.tree, nullptr, ray, false, q, st, sx, kAutoMinLanes, exit_t,
                                                                   kClsHasApex | (0x100u + k), lp);
             if (q) { clear = (c.k == kMiss) | (radius < c.t); n = 1u; }     // render.hpp:117
+#ifdef RTK_DEBUG_PHASES
+            {
+                const float jv[8] = {(float)(__builtin_readcyclecounter() - j0), (float)sx.tally.chunks, (float)sx.tally.surv, (float)sx.tally.tris,
+                                     (float)sx.n_steps, (float)sx.tally.c_cull, (float)sx.tally.c_surv, (float)(sx.n_small + sx.n_big)};
+                for (int i = 0; i < 8; ++i) if (lane == (uint32_t)i) dbg_w = jv[i];
+            }
+#endif
         }
+#ifdef RTK_DEBUG_PHASES
+        sh->result[slice][lane] = make_float4(contrib, clear ? 1.0f : 0.0f, __uint_as_float(n), dbg_w);
+#else
         sh->result[slice][lane] = make_float4(contrib, clear ? 1.0f : 0.0f, __uint_as_float(n), 0.0f);
+#endif
     }
 };
 
@@ -256,6 +273,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
 #ifdef RTK_DEBUG_PHASES
     unsigned long long ph_first_trace = 0, ph_after_first = 0, ph_wait = 0;
     float ph_tr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ph_kind[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float ph_job[3][8] = {{0.f}}, ph_own[1] = {0.f};                 // the helpers' jobs of the last light burst
 #endif
 
     for (;;) {
@@ -532,6 +550,11 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
             }
 #ifdef RTK_DEBUG_PHASES
             ph_wait += __builtin_readcyclecounter() - ph_w0;
+            if (burst && SLICES > 1) {
+                for (int sj = 1; sj < 4 && sj < SLICES; ++sj)
+                    for (int i = 0; i < 8; ++i) ph_job[sj - 1][i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(group_sh->result[sj][i].w)));
+                ph_own[0] = (float)(ph_w0 - tr0);
+            }
             for (int i = 0; i < 6; ++i) if (sx.n_trace == (uint32_t)i) {
                 ph_tr[i] = (float)(__builtin_readcyclecounter() - tr0);
                 ph_kind[i] = burst ? 100.f + (float)burst_plog : (float)__popcll(__builtin_amdgcn_ballot_w64(in_root));
@@ -608,15 +631,18 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     if (valid && writer) {
         const unsigned long long ph_now = __builtin_readcyclecounter();
         const unsigned long long ph_rt1 = __builtin_amdgcn_s_memrealtime();
-        const float vals[35] = {(float)(ph_now - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
+        const float vals[60] = {(float)(ph_now - ph_begin), (float)sx.c_trace, (float)sx.n_trace, (float)sx.n_steps,
                                 (float)sx.n_small, (float)sx.t_small, (float)sx.c_small, (float)sx.n_big, (float)sx.t_big, (float)sx.c_big,
                                 (float)(ph_begin - ph_entry), (float)(ph_first_trace - ph_begin), (float)(ph_after_first - ph_first_trace),
                                 (float)(ph_now - ph_after_first), (float)sx.tally.chunks, (float)sx.tally.surv, (float)sx.tally.tris,
                                 (float)(ph_rt0 & 0xFFFFFFull), (float)(ph_rt1 & 0xFFFFFFull), (float)blockIdx.x,
                                 (float)ph_wait, ph_tr[0], ph_tr[1], ph_tr[2], ph_tr[3], ph_tr[4], ph_tr[5],
-                                ph_kind[0], ph_kind[1], ph_kind[2], ph_kind[3], ph_kind[4], ph_kind[5], (float)sx.c_bund, (float)sx.c_list};
+                                ph_kind[0], ph_kind[1], ph_kind[2], ph_kind[3], ph_kind[4], ph_kind[5], (float)sx.c_bund, (float)sx.c_list, ph_own[0],
+                                ph_job[0][0], ph_job[0][1], ph_job[0][2], ph_job[0][3], ph_job[0][4], ph_job[0][5], ph_job[0][6], ph_job[0][7],
+                                ph_job[1][0], ph_job[1][1], ph_job[1][2], ph_job[1][3], ph_job[1][4], ph_job[1][5], ph_job[1][6], ph_job[1][7],
+                                ph_job[2][0], ph_job[2][1], ph_job[2][2], ph_job[2][3], ph_job[2][4], ph_job[2][5], ph_job[2][6], ph_job[2][7]};
         float v = 0.f;
-        for (int i = 0; i < 35; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
+        for (int i = 0; i < 60; ++i) v = (lane == (uint32_t)i) ? vals[i] : v;
         float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
         o[0] = v; o[1] = 0.f; o[2] = 0.f;
     }

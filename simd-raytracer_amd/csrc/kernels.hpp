@@ -13,7 +13,7 @@ constexpr int kCriticalWord = 8 + kRayCounterShards;   // [kRayCounterShards] lo
 constexpr unsigned long long kCriticalMinTicks = 1000;   // blocks shorter than 10 us do not report (one atomic per block would serialise the frame)
 constexpr int kCounterWords = 8 + 2 * kRayCounterShards;
 constexpr int kCostBins = 64;                      // two-pass frames: log-scale cost bins for longest-first scheduling
-constexpr uint32_t kSliceMinTrisDefault = 65;    // GROUP modes: leaves of at least two 64-triangle chunks are cut across the waves
+constexpr uint32_t kSliceMinTrisDefault = 33;    // GROUP modes: leaves of at least two 64-triangle chunks are cut across the waves
 constexpr size_t kMaxNodeLdsBytes = 48 * 1024;   // node arrays up to this size are staged in LDS (1536 nodes)
 
 }  // namespace rtk

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     const uint32_t n_items = (count + 63u) >> 6;
     Stats st = {0, 0, 0, 0, 0, 0};
     SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u, SLICES > 1 ? group_sh->bundles : nullptr};
+    sx.rebundle = false;
     uint32_t nrays = 0;
 
     for (uint32_t item = gunit; item < n_items; item = LEVEL0 ? n_items : next_item(ctrl + kCtrlTicket + level, n_units_grid)) {
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     const float PI_F = 3.14159265358979323846f;
     Stats st = {0, 0, 0, 0, 0, 0};
     SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u, SLICES > 1 ? group_sh->bundles : nullptr};
+    sx.rebundle = false;
     uint32_t nrays = 0;
 
     for (uint32_t item = gunit; item < n_items; item = next_item(ctrl + kCtrlTicket + kLevels + S.level, n_units_grid)) {

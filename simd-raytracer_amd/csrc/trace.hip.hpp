@@ -296,7 +296,11 @@ struct Bundle {
 enum : uint32_t { BUNDLE_OK = 1u, BUNDLE_ALL_CULL = 2u, BUNDLE_INVX = 4u, BUNDLE_INVY = 8u, BUNDLE_INVZ = 16u, BUNDLE_PENCIL = 32u };
 constexpr float kBundleLimit = 1.0e9f;   // |coordinate| bound under which the interval arithmetic cannot overflow
 constexpr uint32_t kBundleMinTris = 4;   // leaves (or slices) smaller than this are tested triangle by triangle
+#ifndef RTK_SPLIT_LEVELS
+#define RTK_SPLIT_LEVELS 1
+#endif
 constexpr int kMaxBundles = 4;
+constexpr int kBundleSplitLevels = RTK_SPLIT_LEVELS;   // 1: a wide class is cut in two; 2: and its halves once more
 constexpr float kBundleSplitRadius = 0.03f;   // a pencil whose direction box is wider than this (per axis, half width) is cut in two
 constexpr int kBundleFloats = 40;       // see make_bundles for the layout
 constexpr uint32_t kClsHasApex = 0x80000000u;   // bit of the caller's ray class: the `apex` passed along is meaningful
@@ -418,10 +422,8 @@ __device__ __forceinline__ float pencil_delta_lane(const Ray &r, const float cx,
 
 // Bounds + pencil data of the rays of the lanes with `in`, written to bundle slot `n` of `lds`.  Returns the flags (0 = not OK).
 __device__ __forceinline__ uint32_t emit_bundle(const Ray &r, const bool cull, const bool in, const bool hinted, float cx, float cy,
-                                                float cz, float *lds, const uint32_t n, float &widest, uint32_t &widest_axis,
-                                                float &widest_mid) {
+                                                float cz, float *lds, const uint32_t n) {
     const Bundle B = make_bundle(r, cull, in);
-    widest = 0.0f; widest_axis = 0u; widest_mid = 0.0f;
     if ((B.flags & BUNDLE_OK) == 0u) return 0u;
     // fl(1/d) per axis: 1/d is monotone decreasing on either side of zero, and so is its rounding; directions with a
     // tiny or zero component anywhere in the bundle give no bound on that axis (and could overflow the products)
@@ -449,9 +451,6 @@ __device__ __forceinline__ uint32_t emit_bundle(const Ray &r, const bool cull, c
     const float rdx = (B.dhx - B.dlx) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dlx) + __builtin_fabsf(B.dhx));
     const float rdy = (B.dhy - B.dly) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dly) + __builtin_fabsf(B.dhy));
     const float rdz = (B.dhz - B.dlz) * 0.5f * kInfl + kAbs * (__builtin_fabsf(B.dlz) + __builtin_fabsf(B.dhz));
-    widest = rdx; widest_mid = dcx;
-    if (widest < rdy) { widest = rdy; widest_axis = 1u; widest_mid = dcy; }
-    if (widest < rdz) { widest = rdz; widest_axis = 2u; widest_mid = dcz; }
     if (__lane_id() == 0u) {
         float4 *q = reinterpret_cast<float4 *>(lds + n * (uint32_t)kBundleFloats);
         q[0] = make_float4(B.olx, B.oly, B.olz, B.ohx);
@@ -474,10 +473,13 @@ __device__ __forceinline__ uint32_t emit_bundle(const Ray &r, const bool cull, c
     return flags;
 }
 
-// Splits the active lanes by `cls` into at most kMaxBundles bundles (classes beyond that join the last one; a pencil whose
-// directions spread widely -- the two sides of a silhouette -- is cut in two along its widest direction axis while slots are
-// left), writes them to `lds` and tells every lane which bundle its ray belongs to.  Returns the number of bundles, 0 when
-// culling is off for this trace.
+// Splits the active lanes by `cls` into at most kMaxBundles bundles (classes beyond that join the last one), writes them
+// to `lds` and tells every lane which bundle its ray belongs to.  A class whose directions spread widely -- the two sides
+// of a silhouette, reflections fanning out over a mesh, the occlusion queries of hits scattered over it -- is cut along
+// the widest axis of its direction box, and its parts once more, while slots are left: the culling works with the UNION
+// of the bundles' bounds, and four narrow boxes around clusters of rays cover far less than one wide box around them all.
+// (The partition lives in `cidx` itself; any partition is a valid one, the bounds are made from whatever it is.)
+// Returns the number of bundles, 0 when culling is off for this trace.
 __device__ __forceinline__ uint32_t make_bundles(const Ray &r, const bool cull, const bool active, const uint32_t cls,
                                                  const V3 apex, float *lds, uint32_t &cidx) {
     const uint32_t lane = __lane_id();
@@ -489,34 +491,32 @@ __device__ __forceinline__ uint32_t make_bundles(const Ray &r, const bool cull, 
         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, first);
         const bool mine = ((rem >> lane) & 1ull) != 0ull;
         const bool in = mine & ((n == (uint32_t)(kMaxBundles - 1)) | (cls == c));
-        const unsigned long long in_mask = __builtin_amdgcn_ballot_w64(in);
         const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.x), first));
         const float cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.y), first));
         const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(apex.z), first));
         const bool hinted = (c & kClsHasApex) != 0u;
-        float widest, mid;
-        uint32_t axis;
-        const uint32_t flags = emit_bundle(r, cull, in, hinted, cx, cy, cz, lds, n, widest, axis, mid);
-        if (flags == 0u) return 0u;
-        rem &= ~in_mask;
-        // room for one more bundle than the classes still waiting need?  then a wide pencil is cut in two
-        const bool room = n + 2u + (rem != 0ull ? 1u : 0u) <= (uint32_t)kMaxBundles;
-        if (room && (flags & BUNDLE_PENCIL) != 0u && widest > kBundleSplitRadius) {
-            const float dv = axis == 0u ? r.d.x : (axis == 1u ? r.d.y : r.d.z);
-            const bool low = in & (dv <= mid), high = in & !(dv <= mid);
-            if (__builtin_amdgcn_ballot_w64(low) != 0ull && __builtin_amdgcn_ballot_w64(high) != 0ull) {
-                float w2, m2;
-                uint32_t a2;
-                if (emit_bundle(r, cull, low, hinted, cx, cy, cz, lds, n, w2, a2, m2) == 0u) return 0u;
-                if (emit_bundle(r, cull, high, hinted, cx, cy, cz, lds, n + 1u, w2, a2, m2) == 0u) return 0u;
-                if (low) cidx = n;
-                if (high) cidx = n + 1u;
-                n += 2u;
-                continue;
+        rem &= ~__builtin_amdgcn_ballot_w64(in);
+        // slots this class may use: all that are left, minus one for the classes still waiting
+        const uint32_t room = (uint32_t)kMaxBundles - n - (rem != 0ull ? 1u : 0u);
+        uint32_t cnt = 1u;
+        if (in) cidx = n;
+        for (int level = 0; level < kBundleSplitLevels && cnt < room; ++level) {
+            const uint32_t cnt0 = cnt;
+            for (uint32_t b = 0u; b < cnt0 && cnt < room; ++b) {
+                const bool sel = in & (cidx == n + b);
+                const DirSpread S = dir_spread(r, sel);
+                if (!(S.widest > kBundleSplitRadius)) continue;
+                const float dv = S.axis == 0u ? r.d.x : (S.axis == 1u ? r.d.y : r.d.z);
+                const bool high = sel & !(dv <= S.mid);
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(high);
+                if (hm == 0ull || hm == __builtin_amdgcn_ballot_w64(sel)) continue;       // all on one side
+                if (high) cidx = n + cnt;
+                cnt += 1u;
             }
         }
-        if (in) cidx = n;
-        n += 1u;
+        for (uint32_t b = 0u; b < cnt; ++b)
+            if (emit_bundle(r, cull, in & (cidx == n + b), hinted, cx, cy, cz, lds, n + b) == 0u) return 0u;
+        n += cnt;
     }
     return n;
 }
@@ -711,7 +711,7 @@ __device__ __forceinline__ bool pencil_misses(const PencilRegs &R, const float e
 // survivors tested exactly in leaf order.  `cidx` = the bundle of this lane's ray.
 struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
 #ifdef RTK_DEBUG_PHASES
-struct CullTally { uint32_t chunks, surv, tris; };
+struct CullTally { uint32_t chunks, surv, tris; unsigned long long c_cull, c_surv; };
 #define RTK_TALLY_ARG , CullTally &tally
 #define RTK_TALLY_PASS , tally
 #else
@@ -724,6 +724,9 @@ __device__ __forceinline__ void leaf_range_bundle(const float *tris, const uint3
     const unsigned long long pass_mask = __builtin_amdgcn_ballot_w64(pass);
     const uint32_t lane = __lane_id();
     for (uint32_t base = lo; base < hi; base += 64u) {
+#ifdef RTK_DEBUG_PHASES
+        const unsigned long long pc0 = __builtin_readcyclecounter();
+#endif
         const uint32_t cnt = hi - base < 64u ? hi - base : 64u;
         const bool have = lane < cnt;
         const F3 *tp = reinterpret_cast<const F3 *>(tris + (size_t)(first + base + (have ? lane : 0u)) * 9);
@@ -743,6 +746,10 @@ __device__ __forceinline__ void leaf_range_bundle(const float *tris, const uint3
 #ifdef RTK_DEBUG_PHASES
         tally.chunks += 1u; tally.surv += (uint32_t)__popcll(surv); tally.tris += cnt;
 #endif
+#ifdef RTK_DEBUG_PHASES
+        const unsigned long long ps0 = __builtin_readcyclecounter();
+        tally.c_cull += ps0 - pc0;
+#endif
         while (surv != 0ull) {
             const int j = __builtin_ctzll(surv);
             surv &= surv - 1ull;
@@ -758,6 +765,9 @@ __device__ __forceinline__ void leaf_range_bundle(const float *tris, const uint3
             cur.e2z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e2.z), j));
             tri_step(cur, first + base + (uint32_t)j, r, cull, eps, pass_mask, lane, best);
         }
+#ifdef RTK_DEBUG_PHASES
+        tally.c_surv += __builtin_readcyclecounter() - ps0;
+#endif
     }
 }
 
@@ -818,11 +828,14 @@ struct SliceCtx {
     uint32_t work;       // wave-uniform tally of nodes stepped + triangles iterated (a cost estimate for scheduling)
     float *bundle_lds;   // [kMaxBundles * kBundleFloats] floats of LDS for this trace's bundles: sh->bundles when SLICES > 1,
                          // a wave-private area otherwise; nullptr = no bundle culling / leaf-list traversal
+    bool rebundle = true;  // make new bundles when half of a trace's occlusion queries are answered (trace_list).  Pays where
+                         // a trace is long (the megakernel's critical blocks: config 2 -5 %), not in the streaming pipeline's
+                         // sorted queues (configs 3 / 4: +4 %)
 #ifdef RTK_DEBUG_PHASES
     // diagnostic (tools/phase_times.py): cycles and counts of the owner's walk by phase
     unsigned long long c_small = 0, c_big = 0, c_trace = 0, c_bund = 0, c_list = 0;
     uint32_t n_steps = 0, n_small = 0, n_big = 0, t_small = 0, t_big = 0, n_trace = 0;
-    CullTally tally = {0u, 0u, 0u};   // owner's own chunks / survivors / triangles seen by the bundle culling
+    CullTally tally = {0u, 0u, 0u, 0ull, 0ull};   // owner's own chunks / survivors / triangles seen by the bundle culling
 #endif
 };
 #ifdef RTK_DEBUG_PHASES
@@ -831,16 +844,23 @@ struct SliceCtx {
 #define RTK_SX_TALLY
 #endif
 
-// Slice `slice` of a leaf of `count` triangles: contiguous (the merge relies on it) and cut at multiples of 64, so that the
-// bundle culling, which reads 64 triangles at a time, does not run on mostly empty chunks (537 triangles: 9 chunks in all
-// instead of 4 x 3).
+// Slice `slice` of a leaf of `count` triangles: contiguous (the merge relies on it).  A leaf with at least one full
+// 64-triangle pass per wave is cut at multiples of 64, so that the bundle culling, which reads 64 triangles at a time, does
+// not run on mostly empty passes (537 triangles: 9 passes in all instead of 4 x 3); a smaller leaf is cut evenly -- every
+// wave then has one (partly filled) pass and a SLICES-th of the survivors, which is what its time is made of.
 template <int SLICES>
 __device__ __forceinline__ void slice_range(const uint32_t count, const uint32_t slice, uint32_t &lo, uint32_t &hi) {
-    const uint32_t nc = (count + 63u) >> 6;
-    lo = ((nc * slice) / (uint32_t)SLICES) << 6;
-    hi = ((nc * (slice + 1u)) / (uint32_t)SLICES) << 6;
-    lo = lo < count ? lo : count;
-    hi = hi < count ? hi : count;
+    if (count >= 64u * (uint32_t)SLICES) {
+        const uint32_t nc = (count + 63u) >> 6;
+        lo = ((nc * slice) / (uint32_t)SLICES) << 6;
+        hi = ((nc * (slice + 1u)) / (uint32_t)SLICES) << 6;
+        lo = lo < count ? lo : count;
+        hi = hi < count ? hi : count;
+    } else {
+        const uint32_t per = (count + (uint32_t)SLICES - 1u) / (uint32_t)SLICES;
+        lo = slice * per < count ? slice * per : count;
+        hi = lo + per < count ? lo + per : count;
+    }
 }
 
 // helper waves: serve leaf slices (and the kernel's extra jobs) until the owner posts GROUP_EXIT
@@ -853,7 +873,7 @@ __device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared
     uint32_t cidx = 0u;
     BundleSet BS = {sh->bundles, 0u};
 #ifdef RTK_DEBUG_PHASES
-    CullTally tally = {0u, 0u, 0u};
+    CullTally tally = {0u, 0u, 0u, 0ull, 0ull};
 #endif
     for (;;) {
         __syncthreads();                                                   // B1: a command is posted
@@ -967,6 +987,10 @@ __device__ __forceinline__ bool bundle_may_hit_box(const BundleRegs &R, const fl
     return !miss;
 }
 
+#ifndef RTK_REBUNDLE_MIN_LEAVES
+#define RTK_REBUNDLE_MIN_LEAVES 2
+#endif
+constexpr uint32_t kRebundleMinLeaves = RTK_REBUNDLE_MIN_LEAVES;   // new bundles cost about one 64-triangle pass: only with leaves left to use them on
 constexpr uint32_t kListMaxLeaves = 512;    // larger trees keep the hierarchical walk
 
 template <int SLICES>
@@ -1029,7 +1053,7 @@ __device__ __forceinline__ void trace_list(const TreeView &T, const Ray &r, cons
             if (n_live == 0u) return;
             // occlusion queries thin out as they are answered: once half of the rays the bundles were made for are gone, bundles
             // of the remaining ones are tighter (the candidate leaves found with the old bundles stay a valid superset)
-            if (n_live * 2u <= bundled) {
+            if (sx.rebundle && n_live * 2u <= bundled && (uint32_t)__popcll(cm) >= kRebundleMinLeaves) {
 #ifdef RTK_DEBUG_PHASES
                 const unsigned long long pb0 = __builtin_readcyclecounter();
 #endif

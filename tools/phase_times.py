@@ -19,7 +19,7 @@ if world == 1:
     rgb = np.zeros((h, w, 3), np.float32)
     for _ in range(3): assert dbg.rtk_render_frame(ac, C.byref(p), rgb.ctypes.data, C.byref(cn)) == 0
     # lane i of block (by, bx) wrote value i at pixel (by*8 + i//8, bx*8 + i%8)
-    r = rgb[:, :, 0].reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)[:, :35].astype(np.float64)
+    r = rgb[:, :, 0].reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)[:, :60].astype(np.float64)
 else:
     # one rank of a sharded frame: the compact [buckets_per_rank, B, B, 3] buffer; blocks keep their place inside a bucket
     B = int(os.environ.get("TC_BUCKET", "64"))
@@ -32,7 +32,7 @@ else:
         torch.cuda.synchronize()
     buf = dbuf.cpu().numpy()
     bpr = nf.value // (B * B * 3)
-    r = buf.reshape(bpr, B, B, 3)[:, :, :, 0].reshape(bpr, B // 8, 8, B // 8, 8).transpose(0, 1, 3, 2, 4).reshape(-1, 64)[:, :35].astype(np.float64)
+    r = buf.reshape(bpr, B, B, 3)[:, :, :, 0].reshape(bpr, B // 8, 8, B // 8, 8).transpose(0, 1, 3, 2, 4).reshape(-1, 64)[:, :60].astype(np.float64)
     r = r[r[:, 0] > 0]                                       # (blocks of the padding buckets never ran)
     print(f"rank {rank} of {world}: {len(r)} blocks")
 names = ["total", "trace", "n_trace", "steps", "n_small", "t_small", "c_small", "n_big", "t_big", "c_big", "prologue", "to_first_trace", "first_trace", "after_first_trace", "chunks", "surv", "ctris", "rt0", "rt1", "wg"]
@@ -75,4 +75,6 @@ longest = np.argsort(-(end - start))[:8]
 for i in np.argsort(-(end - start))[:6]:
     print("  block %d: %.1f us; burst wait %.1f us; traces (us, kind: 100+log2(parts) = light burst, else rays in the root box): %s" % (
         i, end[i] - start[i], r[i, 20] / 2400.0, [(round(float(r[i, 21 + k]) / 2400.0, 1), int(r[i, 27 + k])) for k in range(6) if r[i, 21 + k] > 0]))
+    print("      last burst: owner's own job %.1f us; helper jobs (us, chunks, survivors, triangles, candidate leaves, culling us, survivors us, leaves): %s" % (
+        r[i, 35] / 2400.0, [tuple([round(float(r[i, 36 + 8 * j]) / 2400.0, 1)] + [int(r[i, 37 + 8 * j + q]) for q in range(4)] + [round(float(r[i, 41 + 8 * j]) / 2400.0, 1), round(float(r[i, 42 + 8 * j]) / 2400.0, 1), int(r[i, 43 + 8 * j])]) for j in range(3)]))
 print("longest (duration us, start us, traces, dispatch index, block y, block x):", [(round(float(end[i] - start[i]), 1), round(float(start[i]), 1), int(r[i, 2]), int(r[i, 19]), int(i // (w // 8)), int(i % (w // 8))) for i in longest])
