@@ -86,27 +86,53 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
 // slicing -- while the owner traces light k (and whatever other rays its lanes have pending).  The owner then adds the
 // contributions in light order, so the float sums are those of the sequential loop.  Four dependent traces become one step.
 // Scenes with transmissive materials keep the sequential loop (a query there may need several segments).
+// The lanes of a burst are dealt to 1, 2 or 4 jobs per light by WHERE their rays go (the widest axis of their directions cut
+// at its middle, the halves once more): a job's time is set by the triangles inside the cone of its rays, so two jobs that
+// each take every other row of the pixel block would each cost as much as the whole (measured), two halves of the cone half.
+// (Halves of equal extent, not of equal counts: a half with a few far-out rays has the whole cone again -- measured too.)
+// Every wave computes the same partition from the same rays.
+__device__ __forceinline__ bool upper_half(const V3 d, const bool sel) {
+    Ray q;
+    q.o = d; q.d = d; q.inv = d;                                            // (only q.d is read)
+    const DirSpread S = dir_spread(q, sel);
+    const float dv = S.axis == 0u ? d.x : (S.axis == 1u ? d.y : d.z);
+    return sel & !(dv <= S.mid);
+}
+__device__ __forceinline__ uint32_t burst_part(const V3 d, const bool in, const uint32_t plog) {
+    uint32_t part = 0u;
+    if (plog == 0u) return part;
+    if (upper_half(d, in)) part = 1u;
+    if (plog >= 2u) {
+#pragma unroll
+        for (uint32_t h = 0u; h < 2u; ++h)
+            if (upper_half(d, in & (part == h))) part |= 2u;
+    }
+    return part;
+}
+
 template <int SLICES>
 struct ShadowBurstService {
     const RenderArgs &A;
+    float4 *res;             // [jobs][64] answers: contribution, clear, flags (bit 0: a ray was traced; bit 1: this job answers for the lane)
+    // Jobs (light, part) are handed out through a counter in LDS: a wave that is done takes the next one, so unequal jobs
+    // (one half of a cone over the mesh, the other past it) even out.  Job 0 is the owner's own.
     __device__ __forceinline__ void operator()(GroupShared *sh, const uint32_t slice) const {
         const uint32_t lane = __lane_id();
-        // job `slice` = (light, part): with fewer lights left than waves the 64 lanes are split into 2 or 4 contiguous
-        // parts (rows of the 8x8 pixel block), each traced by its own wave -- half the lanes make a tighter bundle.
-        const uint32_t plog = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->count);         // log2(parts)
-        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->first) + (slice >> plog);   // this wave's light
-        const uint32_t part = slice & ((1u << plog) - 1u);
+        const uint32_t hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->count);
+        const uint32_t plog = hdr & 0xFFu, n_jobs = hdr >> 8;                                   // log2(parts); lights x parts
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh->first);
         const unsigned long long mask = sh->pass_mask;
-        float contrib = 0.0f;
-        bool clear = true;
-        uint32_t n = 0u;
-#ifdef RTK_DEBUG_PHASES
-        float dbg_w = 0.0f;
-#endif
-        if (k < (uint32_t)A.n_lights) {
+        const float4 a = sh->ray_o[lane], b = sh->ray_d[lane];
+        const V3 P = mk(a.x, a.y, a.z), ncos = mk(a.w, b.x, b.y);
+        const bool in_burst = ((mask >> lane) & 1ull) != 0ull;
+        for (;;) {
+            uint32_t job = 0u;
+            if (lane == 0u) job = atomicAdd(&sh->pad[0], 1u);
+            job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
+            if (job >= n_jobs) break;
+            const uint32_t k = first + (job >> plog);                        // this job's light (< n_lights: the owner counted the jobs)
+            const uint32_t part = job & ((1u << plog) - 1u);
             const float PI_F = 3.14159265358979323846f;
-            const float4 a = sh->ray_o[lane], b = sh->ray_d[lane];
-            const V3 P = mk(a.x, a.y, a.z), ncos = mk(a.w, b.x, b.y);
             const DevLight *L = A.lights + k;                                // wave-uniform
             const V3 lp = mk(L->pos[0], L->pos[1], L->pos[2]);
             V3 ld = lp - P;                                                  // the light loop body of k_render's ST_LIGHT, verbatim
@@ -115,31 +141,20 @@ struct ShadowBurstService {
             ld = normalized(ld);
             const float d0 = dot(ld, ncos);
             const float cosine = (0.0f < d0) ? d0 : 0.0f;
-            contrib = (L->intensity / area) * cosine;
-            const bool q = (((mask >> lane) & 1ull) != 0ull) & ((lane >> (6u - plog)) == part) & (0.0f < radius);   // is_occluded's loop guard, render.hpp:114
+            const float contrib = (L->intensity / area) * cosine;
+            const bool mine = in_burst & (burst_part(ld, in_burst, plog) == part);
+            const bool q = mine & (0.0f < radius);                           // is_occluded's loop guard, render.hpp:114
             const Ray ray = make_ray(P + (A.shadow_bias * ld), ld);
             Stats st = {0, 0, 0, 0, 0, 0};
             SliceCtx sx = {nullptr, 0xFFFFFFFFu, 0u, true, 0u, group_private_bundles<SLICES>(sh, slice)};
             const float exit_t = A.shadow_exit ? radius : -1.0f;
-#ifdef RTK_DEBUG_PHASES
-            const unsigned long long j0 = __builtin_readcyclecounter();
-#endif
             const Cand c = trace<RTK_TRACE_WAVE, false, false, 1>(A.tree, nullptr, ray, false, q, st, sx, kAutoMinLanes, exit_t,
                                                                   kClsHasApex | (0x100u + k), lp);
-            if (q) { clear = (c.k == kMiss) | (radius < c.t); n = 1u; }     // render.hpp:117
-#ifdef RTK_DEBUG_PHASES
-            {
-                const float jv[8] = {(float)(__builtin_readcyclecounter() - j0), (float)sx.tally.chunks, (float)sx.tally.surv, (float)sx.tally.tris,
-                                     (float)sx.n_steps, (float)sx.tally.c_cull, (float)sx.tally.c_surv, (float)(sx.n_small + sx.n_big)};
-                for (int i = 0; i < 8; ++i) if (lane == (uint32_t)i) dbg_w = jv[i];
-            }
-#endif
+            bool clear = true;
+            uint32_t fl = mine ? 2u : 0u;
+            if (q) { clear = (c.k == kMiss) | (radius < c.t); fl |= 1u; }   // render.hpp:117
+            res[job * 64u + lane] = make_float4(contrib, clear ? 1.0f : 0.0f, __uint_as_float(fl), 0.0f);
         }
-#ifdef RTK_DEBUG_PHASES
-        sh->result[slice][lane] = make_float4(contrib, clear ? 1.0f : 0.0f, __uint_as_float(n), dbg_w);
-#else
-        sh->result[slice][lane] = make_float4(contrib, clear ? 1.0f : 0.0f, __uint_as_float(n), 0.0f);
-#endif
     }
 };
 
@@ -205,8 +220,17 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         const uint32_t unit = SLICES > 1 ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
         gwave = (A.order_in != nullptr && unit < A.n_units) ? A.order_in[unit] : unit;
     }
+    // one parking area per wave that can own rays: every wave of a light or SLICES == 1 workgroup, one otherwise -- the
+    // others then hold the answers of a light burst's jobs (ShadowBurstService)
+    constexpr int kParkSlots = 4;                        // light workgroups exist for SLICES == 4 only (api.hip)
+    __shared__ __attribute__((aligned(16))) float park_lds[kParkSlots][18][64];
+    float4 *const burst_res = reinterpret_cast<float4 *>(&park_lds[1][0][0]);
+    // one job per wave: twice as many, handed out as waves fall idle, came out slower (each job pays its own ray setup,
+    // bundles and leaf-list pass, and the owner only ever traces job 0): config 2 0.21 -> 0.255 ms, one rank of eight 0.155 -> 0.18
+    constexpr uint32_t kBurstMaxJobs = SLICES > 8 ? 8u : SLICES > 1 ? (uint32_t)SLICES : 1u;
+    static_assert(SLICES <= 1 || (size_t)kBurstMaxJobs * 64 * sizeof(float4) <= sizeof(float) * (kParkSlots - 1) * 18 * 64, "burst answers fit the spare parking slots");
     if (SLICES > 1 && slice != 0u) {                 // helper waves (trace.hip.hpp, "Workgroup-cooperative leaves")
-        group_helper_loop<SLICES>(A.tree, group_sh, slice, ShadowBurstService<SLICES>{A});
+        group_helper_loop<SLICES>(A.tree, group_sh, slice, ShadowBurstService<SLICES>{A, burst_res});
         return;
     }
     // bundles of the current trace (trace.hip.hpp "Bundle culling"): in the group's shared block when helpers must see them,
@@ -215,8 +239,6 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, light ? 0xFFFFFFFFu : A.slice_min_tris, 0u, true, 0u,
                    (SLICES > 1 && !light) ? group_sh->bundles : wave_bundles[wave_in_wg & 3u]};
     const uint32_t lane = threadIdx.x & 63u;
-    // one parking area per wave that can own rays: every wave of a light or SLICES == 1 workgroup, one otherwise
-    __shared__ float park_lds[4][18][64];                                  // light workgroups exist for SLICES == 4 only (api.hip)
     const uint32_t park_slot = (SLICES > 1 && !light) ? 0u : (wave_in_wg & 3u);
     const unsigned long long cost_t0 = __builtin_readcyclecounter();
     const unsigned long long real_t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, for the frame's critical path (bench.py)
@@ -267,9 +289,9 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     // plane leave the camera's mirror image.  A hint only: wrong or noisy, it loosens the culling and changes no result.
     V3 mirror_apex = black;
     bool burst_done = false;                 // the trace of this iteration ran as a light burst (wave-uniform)
-    uint32_t burst_base = 0u;
     unsigned long long burst_lanes = 0ull;
-    uint32_t burst_shift = 6u;               // lane >> burst_shift = the lane's part of the burst
+    uint32_t burst_plog_done = 0u, burst_part0 = 0u;   // log2(parts) of that burst; this lane's part for its first light
+    uint32_t burst_nl_done = 0u;                       // lights of that burst
 #ifdef RTK_DEBUG_PHASES
     unsigned long long ph_first_trace = 0, ph_after_first = 0, ph_wait = 0;
     float ph_tr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ph_kind[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -476,19 +498,21 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         const bool in_root = kRootFirst ? enters_root(A.tree, ray, need) : need;
         // light burst (ShadowBurstService): every lane about to query a light is at the same light, and more lights follow
         bool burst = false;
-        uint32_t burst_k = 0u, burst_plog = 0u;
+        uint32_t burst_k = 0u, burst_plog = 0u, burst_nl = 0u;
         unsigned long long burst_mask = 0ull;
         bool elsewhere = false;                  // this lane's occlusion query is answered by a helper wave (another part)
+        uint32_t burst_my_part = 0u;
         if (SLICES > 1 && !STATS && !light && A.has_refractive == 0) {
             const bool sh_lane = need & (pend == PEND_SHADOW);
             burst_mask = __builtin_amdgcn_ballot_w64(sh_lane);
             if (burst_mask != 0ull) {
                 burst_k = (uint32_t)__builtin_amdgcn_readlane(light_k, __builtin_ctzll(burst_mask));
                 const uint32_t left = (uint32_t)A.n_lights - burst_k;
-                const uint32_t nl = left < (uint32_t)SLICES ? left : (uint32_t)SLICES;
-                burst_plog = (nl * 4u <= (uint32_t)SLICES) ? 2u : (nl * 2u <= (uint32_t)SLICES) ? 1u : 0u;
-                burst = (__builtin_amdgcn_ballot_w64(sh_lane & ((uint32_t)light_k != burst_k)) == 0ull) & (1u < (nl << burst_plog));
-                elsewhere = burst & sh_lane & ((lane >> (6u - burst_plog)) != 0u);
+                burst_nl = left < kBurstMaxJobs ? left : kBurstMaxJobs;                      // lights of this burst
+                burst_plog = (burst_nl * 4u <= kBurstMaxJobs) ? 2u : (burst_nl * 2u <= kBurstMaxJobs) ? 1u : 0u;
+                burst = (__builtin_amdgcn_ballot_w64(sh_lane & ((uint32_t)light_k != burst_k)) == 0ull) & (1u < (burst_nl << burst_plog));
+                if (burst) burst_my_part = burst_part(ray.d, sh_lane, burst_plog);   // (every shadow lane of a burst is at light burst_k)
+                elsewhere = burst & sh_lane & (burst_my_part != 0u);
             }
         }
         const bool quiet = kRootFirst && !burst && !(PRIMED && wave_any(primed)) && !wave_any(in_root);
@@ -536,7 +560,11 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
             if (burst) {
                 group_sh->ray_o[lane] = make_float4(P.x, P.y, P.z, ncos.x);
                 group_sh->ray_d[lane] = make_float4(ncos.y, ncos.z, 0.f, 0.f);
-                if (lane == 0u) { group_sh->pass_mask = burst_mask; group_sh->first = burst_k; group_sh->count = burst_plog; group_sh->kind = GROUP_EXTRA; }
+                if (lane == 0u) {
+                    group_sh->pass_mask = burst_mask; group_sh->first = burst_k; group_sh->count = burst_plog | ((burst_nl << burst_plog) << 8);
+                    group_sh->pad[0] = 1u;                                  // next job to hand out (job 0 is traced right here)
+                    group_sh->kind = GROUP_EXTRA;
+                }
                 __syncthreads();                                            // B1: the helpers start on their lights
                 sx.min_tris = 0xFFFFFFFFu;                                  // (they are busy: the owner's own leaves stay whole)
             }
@@ -550,17 +578,14 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
             }
 #ifdef RTK_DEBUG_PHASES
             ph_wait += __builtin_readcyclecounter() - ph_w0;
-            if (burst && SLICES > 1) {
-                for (int sj = 1; sj < 4 && sj < SLICES; ++sj)
-                    for (int i = 0; i < 8; ++i) ph_job[sj - 1][i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(group_sh->result[sj][i].w)));
-                ph_own[0] = (float)(ph_w0 - tr0);
-            }
+            if (burst && SLICES > 1) ph_own[0] = (float)(ph_w0 - tr0);
             for (int i = 0; i < 6; ++i) if (sx.n_trace == (uint32_t)i) {
                 ph_tr[i] = (float)(__builtin_readcyclecounter() - tr0);
                 ph_kind[i] = burst ? 100.f + (float)burst_plog : (float)__popcll(__builtin_amdgcn_ballot_w64(in_root));
             }
 #endif
-            burst_done = burst; burst_base = burst_k; burst_lanes = burst_mask; burst_shift = 6u - burst_plog;
+            burst_done = burst; burst_lanes = burst_mask; burst_plog_done = burst_plog; burst_part0 = burst_my_part;
+            burst_nl_done = burst_nl;
 #ifdef RTK_DEBUG_PHASES
             sx.c_trace += __builtin_readcyclecounter() - tr0; sx.n_trace += 1u;
             if (ph_after_first == 0) ph_after_first = __builtin_readcyclecounter();
@@ -582,8 +607,8 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
             if (pend == PEND_SHADOW) {                                       // is_occluded, render.hpp:110-131
                 bool clear = !hit | (shadow_max_t < cand.t);
                 const bool in_burst = SLICES > 1 && burst_done && ((burst_lanes >> lane) & 1ull) != 0ull;
-                const uint32_t my_part = in_burst ? (lane >> burst_shift) : 0u;
-                if (my_part != 0u) clear = group_sh->result[my_part][lane].y != 0.0f;     // light k of the other parts: a helper's answer
+                const uint32_t my_part = in_burst ? burst_part0 : 0u;
+                if (my_part != 0u) clear = burst_res[my_part * 64u + lane].y != 0.0f;     // light k of the other parts: a helper's answer
                 bool again = false;
                 if (!clear && A.has_refractive) {
                     const uint32_t tri = A.tree.tri_ids[cand.k];
@@ -601,14 +626,17 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                     state = ST_LIGHT;
                     if (in_burst) {
                         // the helpers' lights, in light order: the same float sum as the sequential loop
-                        const uint32_t plog = 6u - burst_shift;
-                        for (uint32_t s = 1u; (s << plog) < (uint32_t)SLICES; ++s) {
-                            if (burst_base + s < (uint32_t)A.n_lights) {
-                                const float4 res = group_sh->result[(s << plog) + my_part][lane];
-                                if (res.y != 0.0f) acc = acc + (res.x * albedo);
-                                nrays += __float_as_uint(res.z);
-                                light_k += 1;
+                        const uint32_t plog = burst_plog_done;
+                        for (uint32_t s = 1u; s < burst_nl_done; ++s) {
+                            for (uint32_t pp = 0u; pp < (1u << plog); ++pp) {          // exactly one part answers for this lane
+                                const float4 res = burst_res[((s << plog) + pp) * 64u + lane];
+                                const uint32_t fl = __float_as_uint(res.z);
+                                if ((fl & 2u) != 0u) {
+                                    if (res.y != 0.0f) acc = acc + (res.x * albedo);
+                                    nrays += fl & 1u;
+                                }
                             }
+                            light_k += 1;
                         }
                     }
                 }
