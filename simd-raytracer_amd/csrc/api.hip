@@ -611,6 +611,8 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     const float fov_radians = static_cast<float>(p->fov_degrees * (3.14159265358979323846 / 180.0));
     A.tan_half_fov = std::tan(fov_radians / 2.0f);
     A.spp = p->spp; A.max_depth = p->max_ray_depth; A.diffuse_rays = p->diffuse_rays; A.seed = p->seed;
+    A.width_f = static_cast<float>(g.width); A.height_f = static_cast<float>(g.height);
+    A.spp_f = static_cast<float>(p->spp); A.gi_div_f = static_cast<float>(p->diffuse_rays + 1);
     A.sample_begin = g.sample_begin; A.sample_end = g.sample_end;
     A.shadow_bias = p->shadow_bias; A.reflection_bias = p->reflection_bias; A.refraction_bias = p->refraction_bias;
     A.bucket = g.bucket; A.tiles_x = g.tiles_x; A.tiles_y = g.tiles_y; A.n_buckets = g.n_buckets;
@@ -901,6 +903,7 @@ static int camera_args(rtk_accel *a, const rtk_render_params *p, int32_t sample,
     A.aspect = static_cast<float>(g.width) / static_cast<float>(g.height);
     A.tan_half_fov = std::tan(static_cast<float>(p->fov_degrees * (3.14159265358979323846 / 180.0)) / 2.0f);   // as render_device_impl
     A.spp = p->spp; A.seed = p->seed;
+    A.width_f = static_cast<float>(g.width); A.height_f = static_cast<float>(g.height); A.spp_f = static_cast<float>(p->spp);
     return RTK_OK;
 }
 

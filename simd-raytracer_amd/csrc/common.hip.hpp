@@ -85,7 +85,7 @@ __device__ __forceinline__ Ray camera_ray(const RenderArgs &A, const uint32_t px
         rx += urand_key(key, 0u);
         ry += urand_key(key, 1u);
     }
-    const float ndc_x = rx / (float)A.width, ndc_y = ry / (float)A.height;
+    const float ndc_x = rx / A.width_f, ndc_y = ry / A.height_f;  // render.hpp:43-44 ((float)width, (float)height: RenderArgs)
     float sx = (2.0f * ndc_x) - 1.0f;
     float sy = 1.0f - (2.0f * ndc_y);
     sx *= A.aspect;

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         while (state != ST_TRACE && state != ST_DONE) {
             if (state == ST_NEW_SAMPLE) {                                   // render.hpp:35-69
                 if (sample == A.sample_end) {
-                    const float inv = (float)A.spp;
+                    const float inv = A.spp_f;
                     if (writer) {
                         float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
                         // the last pass divides (render.hpp:72; x / 1.0f == x, bit for bit); earlier passes leave the running sum
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 }
             } else if (state == ST_LIGHT) {                                 // light loop, render.hpp:184-208
                 if (light_k == A.n_lights) {
-                    const float div = (float)(A.diffuse_rays + 1);
+                    const float div = A.gi_div_f;
                     ret = lit_textured ? acc : mk(acc.x / div, acc.y / div, acc.z / div);
                     state = ST_RETURN;
                     continue;

@@ -70,6 +70,8 @@ struct RenderArgs {
     // frame of the same shape starts its blocks most-expensive-first (results do not depend on the order)
     uint32_t n_units;                 // pixel blocks (8x8) of this rank = buckets_per_rank * blocks_per_bucket_side^2
     uint32_t *cost_out;               // [n_units] or null
+    float width_f, height_f, spp_f, gi_div_f;   // (float)width, height, spp, diffuse_rays + 1: wave-uniform, converted once on the host
+                                      // (converted in the kernel they sit in vector registers and are spilled per lane)
     const uint32_t *order_in;         // permutation of the pixel blocks, or null = natural order
     const uint32_t *order_hdr;        // {n_workgroups, n}: see launch_order_by_cost
     const uint32_t *wg_list;          // [n_workgroups] a block id, or 0x80000000 | index into order_in of the first block of a packed workgroup
