@@ -36,7 +36,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 # VALU issue peak: 1024 SIMDs, one wave64 VALU instruction per 2 cycles each (MI355X_MICROARCH.md "Wave scheduling"), 2.4 GHz
 N_SIMDS, CLOCK_GHZ, CYCLES_PER_WAVE_VALU = 1024, 2.4, 2
 VALU_PEAK_GINSTR = N_SIMDS * CLOCK_GHZ / CYCLES_PER_WAVE_VALU
-TRACE_NAMES = {0: "auto", 1: "lane", 2: "wave", 3: "group4", 4: "group8", 5: "group16", 6: "stream", 7: "twopass"}
+TRACE_NAMES = {0: "auto", 1: "lane", 2: "wave", 3: "group4", 4: "group8", 5: "group16", 6: "stream", 7: "twopass", 8: "repack"}
 
 
 def committed_profile():
@@ -131,7 +131,7 @@ def extras(rtk, torch, stream) -> dict:
     for name, rays, cull in (("coherent_primary", coherent, True), ("shuffled_primary", shuffled, True), ("uniform_secondary", secondary, False)):
         cn = acc.intersect_stats(rays.data_ptr(), n, cull, hits.data_ptr(), 2)
         best = None
-        for mode in (2, 0):
+        for mode in (2, 0, 8):      # (0 = auto repacks by itself when its probe finds the batch incoherent; the sort is inside the timed call)
             for _ in range(2):
                 acc.intersect_device(rays.data_ptr(), n, cull, hits.data_ptr(), mode, stream.cuda_stream)
             ms = min(event_ms(torch, stream, lambda: acc.intersect_device(rays.data_ptr(), n, cull, hits.data_ptr(), mode, stream.cuda_stream), 1)
@@ -144,7 +144,8 @@ def extras(rtk, torch, stream) -> dict:
     out["synthetic_2p24"] = {"workload": "SURVEY 8(d): 2^24 rays on scene5's tree through rtk_accel_intersect_device (56 B of ray + hit "
                                          "per ray in HBM); coherent = the 1920x1080 camera rays tiled, shuffled = the same set permuted (seed 42), "
                                          "uniform_secondary = origins uniform in the scene box, directions uniform on the sphere (seed 43); "
-                                         "best of 5 launches, faster of the wave and auto strategies", **synth}
+                                         "best of 5 launches, fastest of the wave, auto and repack strategies (repack: the rays sorted by origin / direction cell "
+                                         "first, the sort inside the timed call)", **synth}
     del coherent, shuffled, secondary, hits, cam
     # ---- one frame each of BASELINE config 3 and of config 4's shape (RTK_TRACE_AUTO picks the engine on the first frames)
     frames = {}

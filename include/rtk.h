@@ -55,8 +55,13 @@ enum {
     RTK_TRACE_GROUP16 = 5, /* frames only: same with 16 waves (one 1024-thread workgroup per 8x8 pixel block) */
     RTK_TRACE_STREAM = 6, /* frames only: the ray tree level by level — per-depth path / shadow / combine kernels over
                              compacted ray queues (stream.hip) */
-    RTK_TRACE_TWOPASS = 7 /* frames only, spp == 1: camera-ray pass, then the GROUP4 shading pass over the pixel blocks
+    RTK_TRACE_TWOPASS = 7, /* frames only, spp == 1: camera-ray pass, then the GROUP4 shading pass over the pixel blocks
                              sorted by estimated cost, most expensive first */
+    RTK_TRACE_REPACK = 8  /* batched intersect only: the rays are first sorted by the cell of their origin and direction
+                             (repack.hip), then traced in that order with the AUTO strategy; hits land in the caller's order,
+                             bit-identical to every other mode.  RTK_TRACE_AUTO does this by itself for batches of at least
+                             2^18 rays whose waves turn out to be incoherent (a probe of every 16th wave; costs one
+                             stream synchronisation); RTK_REPACK=0 in the environment turns that off */
 };
 
 typedef struct rtk_scene rtk_scene;   /* replaces scene<F>, scene/scene.hpp:14-22 */

@@ -26,6 +26,7 @@ RTK_OK, RTK_ERR_INVALID, RTK_ERR_NO_DEVICE, RTK_ERR_HIP, RTK_ERR_IO, RTK_ERR_PAR
 MAT_DIFFUSE, MAT_REFLECTIVE, MAT_REFRACTIVE, MAT_CONSTANT, MAT_TEXTURE = 0, 1, 2, 3, 4
 TEX_ALBEDO, TEX_EDGES, TEX_CHECKER = 0, 1, 2
 TRACE_AUTO, TRACE_LANE, TRACE_WAVE, TRACE_GROUP4, TRACE_GROUP8, TRACE_GROUP16, TRACE_STREAM, TRACE_TWOPASS = 0, 1, 2, 3, 4, 5, 6, 7
+TRACE_REPACK = 8        # batched intersect only: rays sorted by origin / direction cell before the trace (csrc/repack.hip)
 
 # every symbol include/rtk.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [

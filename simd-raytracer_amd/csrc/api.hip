@@ -11,6 +11,7 @@
 
 #include "kernels.hpp"
 #include "stream.hpp"
+#include "repack.hpp"
 
 namespace rtk {
 
@@ -55,6 +56,8 @@ struct rtk_knobs {
     unsigned resort_every = 8;                              // RTK_COST_RESORT_EVERY
     uint32_t light_cycles = 140000u;                        // RTK_LIGHT_BELOW_CYCLES
     uint32_t order_floor_cycles = 20000u;                   // RTK_ORDER_FLOOR_CYCLES
+    bool repack = true;                                     // RTK_REPACK: RTK_TRACE_AUTO may sort large incoherent ray batches
+    int repack_trace = -1;                                  // RTK_REPACK_TRACE: strategy for a sorted batch (0 auto, 1 lane, 2 wave; default: by the probe)
     size_t group8_below = 9000;                             // RTK_GROUP8_BELOW_BLOCKS
     int stream_node_factor = 0;                             // RTK_STREAM_NODE_FACTOR (0 = default)
     int stream_deep_level = 99, stream_deep_mode = RTK_TRACE_AUTO;   // RTK_STREAM_DEEP_LEVEL / _MODE
@@ -76,6 +79,8 @@ struct rtk_knobs {
         if (geti("RTK_COST_RESORT_EVERY", v) && v > 0) k.resort_every = unsigned(v);
         if (geti("RTK_LIGHT_BELOW_CYCLES", v) && v >= 0) k.light_cycles = uint32_t(v);
         if (geti("RTK_ORDER_FLOOR_CYCLES", v) && v >= 0) k.order_floor_cycles = uint32_t(v);
+        if (geti("RTK_REPACK", v)) k.repack = v != 0;
+        if (geti("RTK_REPACK_TRACE", v) && (v == RTK_TRACE_AUTO || v == RTK_TRACE_WAVE || v == RTK_TRACE_LANE)) k.repack_trace = int(v);
         if (geti("RTK_GROUP8_BELOW_BLOCKS", v) && v >= 0) k.group8_below = size_t(v);
         if (geti("RTK_STREAM_NODE_FACTOR", v) && v >= 1) k.stream_node_factor = int(v);
         if (geti("RTK_STREAM_DEEP_LEVEL", v)) k.stream_deep_level = int(v);
@@ -136,6 +141,10 @@ struct rtk_accel {
     int trial_state = 0;
     bool fb_valid = false;           // fb_cost holds the costs of a frame of shape fb_sig
     bool fb_order_valid = false;     // fb_order was made from such costs
+    // ray repacking workspace (batched intersect, repack.hip)
+    uint32_t *rp_bounds = nullptr, *rp_keys = nullptr, *rp_idx = nullptr;
+    void *rp_temp = nullptr;
+    size_t rp_temp_bytes = 0, rp_cap = 0;
     unsigned fb_age = 0;             // frames rendered with the current order
     hipStream_t last_stream = nullptr;
     uint64_t last_primary = 0;
@@ -261,6 +270,7 @@ int ensure_twopass_ws(rtk_accel *a, size_t pixels, size_t tiles) {
 }
 
 bool valid_mode(int m) { return m == RTK_TRACE_AUTO || m == RTK_TRACE_LANE || m == RTK_TRACE_WAVE; }
+bool valid_batch_mode(int m) { return valid_mode(m) || m == RTK_TRACE_REPACK; }
 bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || m == RTK_TRACE_GROUP8 || m == RTK_TRACE_GROUP16 ||
            m == RTK_TRACE_STREAM || m == RTK_TRACE_TWOPASS; }
 
@@ -508,6 +518,7 @@ void rtk_accel_destroy(rtk_accel *a) {
                 if (sd.done[par]) (void)hipEventDestroy(sd.done[par]);
             }
         (void)hipFree(a->tp_prim); (void)hipFree(a->tp_bins); (void)hipFree(a->tp_bin_list); (void)hipFree(a->tp_order);
+        (void)hipFree(a->rp_bounds); (void)hipFree(a->rp_keys); (void)hipFree(a->rp_idx); (void)hipFree(a->rp_temp);
         (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
         for (auto &e : a->trial_ev) if (e) (void)hipEventDestroy(e);
     }
@@ -516,15 +527,58 @@ void rtk_accel_destroy(rtk_accel *a) {
 
 // ---------------------------------------------------------------- batched intersect
 
+// workspace of the ray repacking: keys and indices (double-buffered for the sort), rocPRIM's temporary storage; grows, never shrinks
+static int ensure_repack_ws(rtk_accel *a, size_t n) {
+    if (!a->rp_bounds) RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->rp_bounds), kRepackBoundsWords * sizeof(uint32_t)));
+    if (a->rp_cap >= n) return RTK_OK;
+    (void)hipFree(a->rp_keys); (void)hipFree(a->rp_idx); (void)hipFree(a->rp_temp);
+    a->rp_keys = a->rp_idx = nullptr; a->rp_temp = nullptr; a->rp_cap = 0;
+    size_t tb = 0;
+    RTK_HIP(repack_temp_bytes(n, &tb));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->rp_keys), 2 * n * sizeof(uint32_t)));
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->rp_idx), 2 * n * sizeof(uint32_t)));
+    RTK_HIP(hipMalloc(&a->rp_temp, tb > 0 ? tb : 16));
+    a->rp_temp_bytes = tb; a->rp_cap = n;
+    return RTK_OK;
+}
+
 static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, int cull, int mode, rtk_hit *d_out,
                                  hipStream_t s, bool stats) {
-    if (!valid_mode(mode)) return fail(RTK_ERR_INVALID, "unknown trace_mode");
+    if (!valid_batch_mode(mode)) return fail(RTK_ERR_INVALID, "unknown trace_mode");
     if (n > (size_t(1) << 38)) return fail(RTK_ERR_INVALID, "too many rays for one launch");
     if (n > 0 && (!d_rays || !d_out)) return fail(RTK_ERR_INVALID, "null ray or hit buffer");
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) return fail(RTK_ERR_INVALID, "hit buffer must be 16-byte aligned");
     dev::IntersectArgs A;
     A.tree = tree_view(a);
-    A.rays = d_rays; A.out = d_out; A.n = n; A.cull = cull ? 1 : 0; A.counters = a->d_counters;
+    A.rays = d_rays; A.out = d_out; A.n = n; A.cull = cull ? 1 : 0; A.counters = a->d_counters; A.perm = nullptr;
+    // Ray repacking (repack.hip).  Large batches are probed first (every 16th wave; one stream synchronisation): waves that are
+    // coherent as they come are walked wave-cooperatively; a batch in no useful order is sorted by origin / direction cell and
+    // then walked wave-cooperatively when the sort makes tight waves (three varying dimensions: 10 bits each), with the per-lane
+    // fallback when it cannot (six: 5 bits each).  4 M rays on scene5: shuffled camera rays 4.5 -> 0.47 ms, uniform secondary
+    // rays 11.3 -> 4.1 ms, camera rays in pixel order 0.8 (RTK_TRACE_AUTO before) -> 0.3 ms.
+    const bool big = n >= (size_t(1) << 18) && n < (size_t(1) << 32);
+    const bool forced = mode == RTK_TRACE_REPACK;
+    if (forced) mode = RTK_TRACE_AUTO;
+    if (!stats && ((forced && n >= 2 && n < (size_t(1) << 32)) || (mode == RTK_TRACE_AUTO && a->knobs.repack && big))) {
+        int rc = ensure_repack_ws(a, n);
+        if (rc != RTK_OK) return rc;
+        hipError_t eb = launch_ray_bounds(d_rays, n, a->rp_bounds, forced && !big ? 2u : 16u, s);
+        if (eb != hipSuccess) return hip_fail(eb, "launch k_ray_bounds (probe)");
+        uint32_t h[kRepackBoundsWords];
+        RTK_HIP(hipMemcpyAsync(h, a->rp_bounds, sizeof(h), hipMemcpyDeviceToHost, s));
+        RTK_HIP(hipStreamSynchronize(s));
+        const RepackProbe pr = decode_probe(h);
+        const bool incoherent = pr.wide_dir_fraction >= 0.25f || pr.origin_spread >= 0.25f;
+        if (forced || incoherent) {
+            eb = launch_ray_bounds(d_rays, n, a->rp_bounds, 1u, s);
+            if (eb == hipSuccess) eb = launch_ray_sort(d_rays, n, a->rp_bounds, a->rp_keys, a->rp_idx, a->rp_temp, a->rp_temp_bytes, s);
+            if (eb != hipSuccess) return hip_fail(eb, "ray repacking");
+            A.perm = a->rp_idx + n;
+            mode = a->knobs.repack_trace >= 0 ? a->knobs.repack_trace : (pr.active_dims <= 3 ? RTK_TRACE_WAVE : RTK_TRACE_AUTO);
+        } else {
+            mode = RTK_TRACE_WAVE;                                           // coherent as it comes
+        }
+    }
     const hipError_t e = launch_intersect(A, mode, stats, s);
     if (e != hipSuccess) return hip_fail(e, "launch k_intersect");
     return RTK_OK;

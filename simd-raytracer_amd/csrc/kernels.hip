@@ -42,8 +42,9 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
     DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
     if (LDS_NODES) stage_nodes(A.tree.nodes, A.tree.n_nodes, lds_nodes);
 
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < A.n;
+    const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = slot < A.n;
+    const size_t i = (active && A.perm != nullptr) ? (size_t)A.perm[slot] : slot;      // repacked batches: the ray this slot was dealt
     Ray r;
     if (active) {
         const float *p = reinterpret_cast<const float *>(A.rays + i);

@@ -28,6 +28,7 @@ struct IntersectArgs {
     const rtk_ray *rays;
     rtk_hit *out;
     size_t n;
+    const uint32_t *perm;             // lane i takes ray perm[i] and writes hit perm[i] (repack.hip); null = identity
     int cull;
     unsigned long long *counters;
 };

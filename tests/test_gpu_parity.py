@@ -12,8 +12,8 @@ from conftest import CONFIG_SCENES, SCENE2, SCENE5, SCENE8
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-MODES = {"auto": 0, "lane": 1, "wave": 2}                       # batched intersect
-FRAME_MODES = {**MODES, "group4": 3, "group8": 4, "group16": 5, "stream": 6, "twopass": 7}   # frames: + workgroup-cooperative leaves, streaming pipeline
+MODES = {"auto": 0, "lane": 1, "wave": 2, "repack": 8}          # batched intersect (repack: rays sorted by cell first, csrc/repack.hip)
+FRAME_MODES = {"auto": 0, "lane": 1, "wave": 2, "group4": 3, "group8": 4, "group16": 5, "stream": 6, "twopass": 7}   # frames: + workgroup-cooperative leaves, streaming pipeline
 
 
 def _bits(a):
@@ -128,6 +128,34 @@ def test_intersect_ragged_sizes(rtk, ora, n):
         assert got.shape == (n,)
         assert np.array_equal(got["tri"], ref["tri"])
         assert np.array_equal(_bits(got["t"]), _bits(ref["t"]))
+
+
+def test_large_incoherent_batches_are_repacked_without_changing_a_bit(rtk, ora):
+    """2^19 rays in no useful order: RTK_TRACE_AUTO probes the batch, finds it incoherent and sorts it (csrc/repack.hip);
+    RTK_TRACE_REPACK sorts unconditionally.  Hits must land in the caller's order with the bits of the unsorted walk, and
+    of the oracle on a sample.  A coherent batch of the same size (AUTO's probe says no) and degenerate batches (all rays
+    equal; NaN rays) go through the same entry points."""
+    acc, oacc = _scene_pair(rtk, ora, SCENE5)
+    n = 1 << 19
+    rng = np.random.default_rng(7)
+    cam = acc.camera_rays(rtk.RenderConfig(width=1024, height=512), 0).reshape(-1, 6)            # 2^19 pixel-centre rays, row-major
+    assert cam.shape[0] == n
+    sets = {"coherent": cam, "shuffled": cam[rng.permutation(n)],
+            "mixed": _mixed_rays(oacc.scene.flat, n, seed=11)[rng.permutation(n)]}
+    same = np.repeat(cam[12345:12346], 70_000, axis=0)
+    bad = cam[:70_000].copy(); bad[::97, 3] = np.nan; bad[5::131, 0] = np.inf
+    sets["all_equal"] = same
+    sets["nan_inf"] = bad
+    for name, rays in sets.items():
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        ref = acc.intersect(rays, True, MODES["wave"])
+        for mode in ("auto", "repack"):
+            got = acc.intersect(rays, True, MODES[mode])
+            assert got.tobytes() == ref.tobytes(), (name, mode)
+        k = 40_000
+        o = oacc.intersect(rays[:k], True)
+        assert np.array_equal(ref["tri"][:k], o["tri"]) and np.array_equal(_bits(ref["t"][:k]), _bits(o["t"])), name
+    assert (acc.intersect(np.ascontiguousarray(sets["shuffled"]), True, MODES["repack"])["tri"] != 0xFFFFFFFF).sum() > 10_000
 
 
 def test_intersect_unnormalized_normal_matches_kd_tree_accel(rtk, ora):
