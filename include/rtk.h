@@ -44,7 +44,9 @@ enum { RTK_TEX_ALBEDO = 0, RTK_TEX_EDGES = 1, RTK_TEX_CHECKER = 2 };
 
 /* traversal strategy of the device kernels; all of them give bit-identical results */
 enum {
-    RTK_TRACE_AUTO = 0,   /* batched intersect: wave-cooperative while the wave's rays agree, per-lane otherwise;
+    RTK_TRACE_AUTO = 0,   /* batched intersect: wave-cooperative while the wave's rays agree, per-lane otherwise; batches of
+                             2^18 rays and more are probed first (every 16th wave of 64 rays; one stream synchronisation):
+                             coherent as they come -> RTK_TRACE_WAVE, in no useful order -> sorted first (RTK_TRACE_REPACK);
                              frames: the GROUP4 megakernel (GROUP8 when the frame has few pixel blocks); scenes whose ray trees
                              fork (refraction, diffuse GI) are timed through RTK_TRACE_STREAM and the megakernel on their first
                              frames and keep the faster */
@@ -58,10 +60,11 @@ enum {
     RTK_TRACE_TWOPASS = 7, /* frames only, spp == 1: camera-ray pass, then the GROUP4 shading pass over the pixel blocks
                              sorted by estimated cost, most expensive first */
     RTK_TRACE_REPACK = 8  /* batched intersect only: the rays are first sorted by the cell of their origin and direction
-                             (repack.hip), then traced in that order with the AUTO strategy; hits land in the caller's order,
-                             bit-identical to every other mode.  RTK_TRACE_AUTO does this by itself for batches of at least
-                             2^18 rays whose waves turn out to be incoherent (a probe of every 16th wave; costs one
-                             stream synchronisation); RTK_REPACK=0 in the environment turns that off */
+                             (repack.hip: Morton key over the dimensions that vary, rocPRIM radix sort), then traced in that
+                             order -- wave-cooperatively when the sort makes tight waves, with the per-lane fallback otherwise;
+                             hits land in the caller's order, bit-identical to every other mode.  Needs 16 B of workspace
+                             per ray (kept by the accel).  RTK_TRACE_AUTO does this by itself for large incoherent batches;
+                             RTK_REPACK=0 in the environment turns that off */
 };
 
 typedef struct rtk_scene rtk_scene;   /* replaces scene<F>, scene/scene.hpp:14-22 */
