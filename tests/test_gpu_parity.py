@@ -212,6 +212,45 @@ def test_render_gate_a(rtk, ora, case, mode):
     assert delta == 0.0, f"within tolerance but not bit-exact: {delta}"
 
 
+@pytest.mark.parametrize("n_lights", [1, 2, 3, 5, 9])
+def test_light_bursts_with_any_number_of_lights(rtk, ora, n_lights, tmp_path):
+    """The light loop (render.hpp:184-206) runs as bursts of jobs (light, part of the lanes) over the waves of a workgroup:
+    one light -> four parts, two -> two each, more lights than waves -> several bursts.  scene5 with its lights replaced by
+    1 .. 9 lights around the dragon, in every frame mode that has helpers and in the sequential ones; bit-exact vs the oracle,
+    also sharded eight ways (few blocks per rank -> RTK_TRACE_AUTO takes the 8-wave workgroups)."""
+    import json
+    doc = json.load(open(SCENE5))
+    base = doc["lights"]
+    doc["lights"] = [{"intensity": base[i % len(base)]["intensity"] * (0.5 + 0.25 * (i % 3)),
+                      "position": [float(9 - 4 * i), float(7 + (i * 5) % 11), float(-3 + 2 * (i % 4))]} for i in range(n_lights)]
+    path = str(tmp_path / f"scene5_{n_lights}_lights.crtscene")
+    json.dump(doc, open(path, "w"))
+    acc, oacc = _scene_pair(rtk, ora, path)
+    w, h = 320, 184
+    ref, ocn = oacc.render(w, h, 1, 5, 0)
+    for mode in ("auto", "group4", "group8", "group16", "wave", "stream"):
+        rgb, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h, max_ray_depth=5, trace_mode=FRAME_MODES[mode]))
+        assert cn["rays"] == ocn["rays"], mode
+        assert np.array_equal(_bits(rgb), _bits(ref)), (mode, float(np.max(np.abs(rgb - ref))))
+    # a repeated frame (cost feedback: packed and single-block workgroups side by side) ...
+    for _ in range(3):
+        rgb, _ = acc.render_frame(rtk.RenderConfig(width=w, height=h, max_ray_depth=5, trace_mode=FRAME_MODES["group4"]))
+        assert np.array_equal(_bits(rgb), _bits(ref))
+    # ... and the frame sharded eight ways, twice (the second time with the ranks' own block orders)
+    import torch
+    world = 8
+    cfgs = [rtk.RenderConfig(width=w, height=h, max_ray_depth=5, rank=r, world_size=world) for r in range(world)]
+    gathered = torch.full((world, acc.output_floats(cfgs[0])), float("nan"), dtype=torch.float32, device="cuda")
+    out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        for r in range(world):
+            acc.render_frame_device(cfgs[r], gathered[r].data_ptr(), stream)
+        acc.assemble_device(cfgs[0], gathered.data_ptr(), out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref))
+
+
 @pytest.mark.parametrize("scene", list(CONFIG_SCENES))
 def test_render_gate_b_kd_tree_accel(rtk, ora, scene):
     """Gate B (BASELINE wording): normalize_hit_normal=0 vs the CPU kd_tree_accel render, |delta| < 1e-4."""
