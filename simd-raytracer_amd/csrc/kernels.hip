@@ -667,7 +667,8 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                                 (float)(ph_rt0 & 0xFFFFFFull), (float)(ph_rt1 & 0xFFFFFFull), (float)blockIdx.x,
                                 (float)ph_wait, ph_tr[0], ph_tr[1], ph_tr[2], ph_tr[3], ph_tr[4], ph_tr[5],
                                 ph_kind[0], ph_kind[1], ph_kind[2], ph_kind[3], ph_kind[4], ph_kind[5], (float)sx.c_bund, (float)sx.c_list, ph_own[0],
-                                ph_job[0][0], ph_job[0][1], ph_job[0][2], ph_job[0][3], ph_job[0][4], ph_job[0][5], ph_job[0][6], ph_job[0][7],
+                                (float)sx.tally.stg.n, (float)sx.tally.stg.w1, (float)sx.tally.stg.l1, (float)sx.tally.stg.w2, (float)sx.tally.stg.l2,
+                                (float)sx.tally.stg.w3, (float)sx.tally.stg.l3, (float)sx.tally.stg.l4,
                                 ph_job[1][0], ph_job[1][1], ph_job[1][2], ph_job[1][3], ph_job[1][4], ph_job[1][5], ph_job[1][6], ph_job[1][7],
                                 ph_job[2][0], ph_job[2][1], ph_job[2][2], ph_job[2][3], ph_job[2][4], ph_job[2][5], ph_job[2][6], ph_job[2][7]};
         float v = 0.f;

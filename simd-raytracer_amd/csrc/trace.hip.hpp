@@ -204,8 +204,17 @@ __device__ __forceinline__ TriS load_tri_uniform(cptr_f32 tp) {
 }
 
 // one triangle against the wave's rays (the arithmetic of test_triangle, wave-level early outs between the stages)
+#ifdef RTK_DEBUG_PHASES
+struct StageTally { uint32_t n, w1, l1, w2, l2, w3, l3, l4; };   // triangles; waves / lanes alive after det+u_est, after u, after v; lanes accepted
+#define RTK_STAGE_ARG , StageTally *stg = nullptr
+#define RTK_STAGE(x) if (stg) { x; }
+#else
+#define RTK_STAGE_ARG
+#define RTK_STAGE(x)
+#endif
 __device__ __forceinline__ void tri_step(const TriS &cur, const uint32_t k, const Ray &r, const bool cull, const float eps,
-                                         const unsigned long long pass_mask, const uint32_t lane, Cand &best) {
+                                         const unsigned long long pass_mask, const uint32_t lane, Cand &best RTK_STAGE_ARG) {
+    RTK_STAGE(stg->n += 1u)
     const float pvx = r.d.y * cur.e2z - r.d.z * cur.e2y;
     const float pvy = r.d.z * cur.e2x - r.d.x * cur.e2z;
     const float pvz = r.d.x * cur.e2y - r.d.y * cur.e2x;
@@ -222,19 +231,23 @@ __device__ __forceinline__ void tri_step(const TriS &cur, const uint32_t k, cons
     const float u_est = un * __builtin_amdgcn_rcpf(det);
     m &= ~(__builtin_amdgcn_ballot_w64(u_est < -1.0e-30f) | __builtin_amdgcn_ballot_w64(1.00001f < u_est));
     if (m == 0ull) return;
+    RTK_STAGE(stg->w1 += 1u; stg->l1 += (uint32_t)__popcll(m))
     const float inv_det = (1.0f / det);
     const float u = un * inv_det;
     m &= __builtin_amdgcn_ballot_w64(0.0f <= u) & __builtin_amdgcn_ballot_w64(u <= 1.0f);
     if (m == 0ull) return;
+    RTK_STAGE(stg->w2 += 1u; stg->l2 += (uint32_t)__popcll(m))
     const float qx = tvy * cur.e1z - tvz * cur.e1y;
     const float qy = tvz * cur.e1x - tvx * cur.e1z;
     const float qz = tvx * cur.e1y - tvy * cur.e1x;
     const float v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv_det;
     m &= __builtin_amdgcn_ballot_w64(0.0f <= v) & __builtin_amdgcn_ballot_w64(u + v <= 1.0f);
     if (m == 0ull) return;
+    RTK_STAGE(stg->w3 += 1u; stg->l3 += (uint32_t)__popcll(m))
     const float t = (cur.e2x * qx + cur.e2y * qy + cur.e2z * qz) * inv_det;
     m &= __builtin_amdgcn_ballot_w64(eps < t) & __builtin_amdgcn_ballot_w64(t < best.t);
     if (m == 0ull) return;
+    RTK_STAGE(stg->l4 += (uint32_t)__popcll(m))
     if ((m >> lane) & 1ull) { best.t = t; best.u = u; best.v = v; best.k = k; }
 }
 
@@ -711,7 +724,7 @@ __device__ __forceinline__ bool pencil_misses(const PencilRegs &R, const float e
 // survivors tested exactly in leaf order.  `cidx` = the bundle of this lane's ray.
 struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
 #ifdef RTK_DEBUG_PHASES
-struct CullTally { uint32_t chunks, surv, tris; unsigned long long c_cull, c_surv; };
+struct CullTally { uint32_t chunks, surv, tris; unsigned long long c_cull, c_surv; StageTally stg; };
 #define RTK_TALLY_ARG , CullTally &tally
 #define RTK_TALLY_PASS , tally
 #else
@@ -763,7 +776,11 @@ __device__ __forceinline__ void leaf_range_bundle(const float *tris, const uint3
             cur.e2x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e2.x), j));
             cur.e2y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e2.y), j));
             cur.e2z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e2.z), j));
+#ifdef RTK_DEBUG_PHASES
+            tri_step(cur, first + base + (uint32_t)j, r, cull, eps, pass_mask, lane, best, &tally.stg);
+#else
             tri_step(cur, first + base + (uint32_t)j, r, cull, eps, pass_mask, lane, best);
+#endif
         }
 #ifdef RTK_DEBUG_PHASES
         tally.c_surv += __builtin_readcyclecounter() - ps0;
@@ -835,7 +852,7 @@ struct SliceCtx {
     // diagnostic (tools/phase_times.py): cycles and counts of the owner's walk by phase
     unsigned long long c_small = 0, c_big = 0, c_trace = 0, c_bund = 0, c_list = 0;
     uint32_t n_steps = 0, n_small = 0, n_big = 0, t_small = 0, t_big = 0, n_trace = 0;
-    CullTally tally = {0u, 0u, 0u, 0ull, 0ull};   // owner's own chunks / survivors / triangles seen by the bundle culling
+    CullTally tally = {0u, 0u, 0u, 0ull, 0ull, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};   // owner's own chunks / survivors / triangles seen by the bundle culling
 #endif
 };
 #ifdef RTK_DEBUG_PHASES
@@ -873,7 +890,7 @@ __device__ __forceinline__ void group_helper_loop(const TreeView &T, GroupShared
     uint32_t cidx = 0u;
     BundleSet BS = {sh->bundles, 0u};
 #ifdef RTK_DEBUG_PHASES
-    CullTally tally = {0u, 0u, 0u, 0ull, 0ull};
+    CullTally tally = {0u, 0u, 0u, 0ull, 0ull, {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
 #endif
     for (;;) {
         __syncthreads();                                                   // B1: a command is posted

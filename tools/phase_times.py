@@ -46,6 +46,11 @@ def show(tag, m):
           f"sliced leaves {d['n_big']/n:.1f} with {d['t_big']/n:.0f} tris ({d['c_big']/max(d['n_big'],1):.0f} cyc/leaf, {d['c_big']/max(d['t_big'],1):.0f} cyc/tri)")
     print(f"    of the total: waiting for the helpers of a light burst {100*r[m][:,20].sum()/d['total']:.0f}%, making bundles {100*r[m][:,33].sum()/d['total']:.0f}%, "
           f"culling the leaf list {100*r[m][:,34].sum()/d['total']:.0f}%")
+    g = r[m][:, 36:44].sum(0)
+    if g[0] > 0:
+        print(f"    owner's exact tests: {g[0]/n:.0f} surviving triangles per block; the wave goes on after det + u estimate for {100*g[1]/g[0]:.0f}% "
+              f"({g[2]/max(g[1],1):.1f} lanes alive), after u for {100*g[3]/g[0]:.0f}% ({g[4]/max(g[3],1):.1f}), after v for {100*g[5]/g[0]:.0f}% ({g[6]/max(g[5],1):.1f}); "
+              f"{g[7]/g[0]:.2f} accepted lanes per triangle")
     print(f"    owner's bundle culling per block: {d['chunks']/n:.1f} chunks, {d['ctris']/n:.0f} triangles in, {d['surv']/n:.1f} survivors ({100*d['surv']/max(d['ctris'],1):.1f}%)")
 tot = r[:, 0]
 bg = (r[:, 2] == 1) & (r[:, 4] + r[:, 7] == 0)
@@ -75,6 +80,4 @@ longest = np.argsort(-(end - start))[:8]
 for i in np.argsort(-(end - start))[:6]:
     print("  block %d: %.1f us; burst wait %.1f us; traces (us, kind: 100+log2(parts) = light burst, else rays in the root box): %s" % (
         i, end[i] - start[i], r[i, 20] / 2400.0, [(round(float(r[i, 21 + k]) / 2400.0, 1), int(r[i, 27 + k])) for k in range(6) if r[i, 21 + k] > 0]))
-    print("      last burst: owner's own job %.1f us; helper jobs (us, chunks, survivors, triangles, candidate leaves, culling us, survivors us, leaves): %s" % (
-        r[i, 35] / 2400.0, [tuple([round(float(r[i, 36 + 8 * j]) / 2400.0, 1)] + [int(r[i, 37 + 8 * j + q]) for q in range(4)] + [round(float(r[i, 41 + 8 * j]) / 2400.0, 1), round(float(r[i, 42 + 8 * j]) / 2400.0, 1), int(r[i, 43 + 8 * j])]) for j in range(3)]))
 print("longest (duration us, start us, traces, dispatch index, block y, block x):", [(round(float(end[i] - start[i]), 1), round(float(start[i]), 1), int(r[i, 2]), int(r[i, 19]), int(i // (w // 8)), int(i % (w // 8))) for i in longest])
