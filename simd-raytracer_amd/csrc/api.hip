@@ -56,6 +56,7 @@ struct rtk_knobs {
     unsigned resort_every = 8;                              // RTK_COST_RESORT_EVERY
     uint32_t light_cycles = 140000u;                        // RTK_LIGHT_BELOW_CYCLES
     uint32_t order_floor_cycles = 20000u;                   // RTK_ORDER_FLOOR_CYCLES
+    bool stream_scalar_surv = true;                         // RTK_STREAM_SCALAR_SURV: survivors through the scalar cache in the streaming kernels
     bool repack = true;                                     // RTK_REPACK: RTK_TRACE_AUTO may sort large incoherent ray batches
     int repack_trace = -1;                                  // RTK_REPACK_TRACE: strategy for a sorted batch (0 auto, 1 lane, 2 wave; default: by the probe)
     size_t group8_below = 9000;                             // RTK_GROUP8_BELOW_BLOCKS
@@ -80,6 +81,7 @@ struct rtk_knobs {
         if (geti("RTK_LIGHT_BELOW_CYCLES", v) && v >= 0) k.light_cycles = uint32_t(v);
         if (geti("RTK_ORDER_FLOOR_CYCLES", v) && v >= 0) k.order_floor_cycles = uint32_t(v);
         if (geti("RTK_REPACK", v)) k.repack = v != 0;
+        if (geti("RTK_STREAM_SCALAR_SURV", v)) k.stream_scalar_surv = v != 0;
         if (geti("RTK_REPACK_TRACE", v) && (v == RTK_TRACE_AUTO || v == RTK_TRACE_WAVE || v == RTK_TRACE_LANE)) k.repack_trace = int(v);
         if (geti("RTK_GROUP8_BELOW_BLOCKS", v) && v >= 0) k.group8_below = size_t(v);
         if (geti("RTK_STREAM_NODE_FACTOR", v) && v >= 1) k.stream_node_factor = int(v);
@@ -195,6 +197,7 @@ dev::TreeView tree_view(const rtk_accel *a) {
     t.eps = a->params.eps;
     t.normalize = a->params.normalize_hit_normal;
     t.bundle_cull = (a->knobs.bundle_cull && a->coords_small) ? 1 : 0;
+    t.scalar_surv = 0;
     return t;
 }
 
@@ -745,7 +748,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         rc = ensure_stream_ws(a, out_pixels, n_root * factor + 4096, a->scene.lights.size(), p->spp > 1, lanes);
         if (rc != RTK_OK) return rc;
         dev::StreamArgs S;
-        S.r = A; S.ws = a->ws; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root); S.auto_min_lanes = a->knobs.auto_min_lanes;
+        S.r = A; S.r.tree.scalar_surv = a->knobs.stream_scalar_surv ? 1 : 0; S.ws = a->ws; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root); S.auto_min_lanes = a->knobs.auto_min_lanes;
         S.n_lanes = uint32_t(lanes);
         for (int j = 0; j < dev::kStreamLanes; ++j) S.lane_overflow[j] = a->ws_lane[j < lanes ? j : 0].ctrl + dev::kCtrlOverflow;
         // measured on MI355X: the workgroup-cooperative wave walk beats the per-lane walk at every depth, even for the

@@ -63,6 +63,7 @@ struct TreeView {
     float eps;
     int normalize;
     int bundle_cull;             // 1: leaves may be pre-culled against the wave's ray bundle (all vertex coordinates are small enough)
+    int scalar_surv;             // 1: a culling pass's survivors are re-read through the scalar cache instead of v_readlane (leaf_range_bundle)
 };
 
 // Wave-uniform loads: address space 4 (constant) forces s_load_* through the scalar cache, so one
@@ -733,7 +734,7 @@ struct CullTally { uint32_t chunks, surv, tris; unsigned long long c_cull, c_sur
 #endif
 __device__ __forceinline__ void leaf_range_bundle(const float *tris, const uint32_t first, const uint32_t lo, const uint32_t hi,
                                                   const Ray &r, const bool cull, const float eps, const bool pass,
-                                                  const uint32_t cidx, const BundleSet &BS, Cand &best RTK_TALLY_ARG) {
+                                                  const uint32_t cidx, const BundleSet &BS, const bool scalar_surv, Cand &best RTK_TALLY_ARG) {
     const unsigned long long pass_mask = __builtin_amdgcn_ballot_w64(pass);
     const uint32_t lane = __lane_id();
     for (uint32_t base = lo; base < hi; base += 64u) {
@@ -763,6 +764,30 @@ __device__ __forceinline__ void leaf_range_bundle(const float *tris, const uint3
         const unsigned long long ps0 = __builtin_readcyclecounter();
         tally.c_cull += ps0 - pc0;
 #endif
+        // the survivors, in leaf order.  Their data is broadcast from the lane that holds it (nine v_readlane), or -- scalar_surv,
+        // the streaming kernels -- comes back through the scalar cache (one 32-byte + one 4-byte s_load each, the next
+        // survivor's issued before the current one is tested): the readlanes are VALU issue slots, which a lone wave runs out
+        // of first (configs 3 / 4: -5 %), but under the megakernel's full occupancy the scalar cache is the scarcer (config 2: +9 %).
+        if (scalar_surv) {
+            if (surv != 0ull) {
+                cptr_f32 tb = (cptr_f32)(const void *)tris + (size_t)(first + base) * 9;
+                int j = __builtin_ctzll(surv);
+                surv &= surv - 1ull;
+                TriS cur = load_tri_uniform(tb + (size_t)j * 9);
+                for (;;) {
+                    const int jn = surv != 0ull ? __builtin_ctzll(surv) : j;
+                    const TriS nxt = load_tri_uniform(tb + (size_t)jn * 9);
+#ifdef RTK_DEBUG_PHASES
+                    tri_step(cur, first + base + (uint32_t)j, r, cull, eps, pass_mask, lane, best, &tally.stg);
+#else
+                    tri_step(cur, first + base + (uint32_t)j, r, cull, eps, pass_mask, lane, best);
+#endif
+                    if (surv == 0ull) break;
+                    surv &= surv - 1ull;
+                    cur = nxt; j = jn;
+                }
+            }
+        } else {
         while (surv != 0ull) {
             const int j = __builtin_ctzll(surv);
             surv &= surv - 1ull;
@@ -782,6 +807,7 @@ __device__ __forceinline__ void leaf_range_bundle(const float *tris, const uint3
             tri_step(cur, first + base + (uint32_t)j, r, cull, eps, pass_mask, lane, best);
 #endif
         }
+        }
 #ifdef RTK_DEBUG_PHASES
         tally.c_surv += __builtin_readcyclecounter() - ps0;
 #endif
@@ -794,7 +820,7 @@ __device__ __forceinline__ void leaf_range(const TreeView &T, const uint32_t fir
                                            const BundleSet &BS, Cand &best RTK_TALLY_ARG) {
     if (lo >= hi) return;
     if (BS.n != 0u && hi - lo >= kBundleMinTris)
-        leaf_range_bundle(reinterpret_cast<const float *>(T.tris), first, lo, hi, r, cull, T.eps, pass, cidx, BS, best RTK_TALLY_PASS);
+        leaf_range_bundle(reinterpret_cast<const float *>(T.tris), first, lo, hi, r, cull, T.eps, pass, cidx, BS, T.scalar_surv != 0, best RTK_TALLY_PASS);
     else
         leaf_range_wave((cptr_f32)(const void *)T.tris, first, lo, hi, r, cull, T.eps, pass, best);
 }
