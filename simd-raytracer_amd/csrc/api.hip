@@ -56,6 +56,7 @@ struct rtk_knobs {
     unsigned resort_every = 8;                              // RTK_COST_RESORT_EVERY
     uint32_t light_cycles = 140000u;                        // RTK_LIGHT_BELOW_CYCLES
     uint32_t order_floor_cycles = 20000u;                   // RTK_ORDER_FLOOR_CYCLES
+    bool batch_scalar_surv = false;                         // RTK_BATCH_SCALAR_SURV: the same in the batched intersect
     bool stream_scalar_surv = true;                         // RTK_STREAM_SCALAR_SURV: survivors through the scalar cache in the streaming kernels
     bool repack = true;                                     // RTK_REPACK: RTK_TRACE_AUTO may sort large incoherent ray batches
     int repack_trace = -1;                                  // RTK_REPACK_TRACE: strategy for a sorted batch (0 auto, 1 lane, 2 wave; default: by the probe)
@@ -82,6 +83,7 @@ struct rtk_knobs {
         if (geti("RTK_ORDER_FLOOR_CYCLES", v) && v >= 0) k.order_floor_cycles = uint32_t(v);
         if (geti("RTK_REPACK", v)) k.repack = v != 0;
         if (geti("RTK_STREAM_SCALAR_SURV", v)) k.stream_scalar_surv = v != 0;
+        if (geti("RTK_BATCH_SCALAR_SURV", v)) k.batch_scalar_surv = v != 0;
         if (geti("RTK_REPACK_TRACE", v) && (v == RTK_TRACE_AUTO || v == RTK_TRACE_WAVE || v == RTK_TRACE_LANE)) k.repack_trace = int(v);
         if (geti("RTK_GROUP8_BELOW_BLOCKS", v) && v >= 0) k.group8_below = size_t(v);
         if (geti("RTK_STREAM_NODE_FACTOR", v) && v >= 1) k.stream_node_factor = int(v);
@@ -554,6 +556,7 @@ static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, 
     dev::IntersectArgs A;
     A.tree = tree_view(a);
     A.rays = d_rays; A.out = d_out; A.n = n; A.cull = cull ? 1 : 0; A.counters = a->d_counters; A.perm = nullptr;
+    A.tree.scalar_surv = a->knobs.batch_scalar_surv ? 1 : 0;
     // Ray repacking (repack.hip).  Large batches are probed first (every 16th wave; one stream synchronisation): waves that are
     // coherent as they come are walked wave-cooperatively; a batch in no useful order is sorted by origin / direction cell and
     // then walked wave-cooperatively when the sort makes tight waves (three varying dimensions: 10 bits each), with the per-lane
