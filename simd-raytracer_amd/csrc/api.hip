@@ -53,7 +53,7 @@ struct rtk_knobs {
     bool bundle_cull = true;                                // RTK_BUNDLE_CULL
     bool auto_trials = true;                                // RTK_AUTO_TRIALS
     bool cost_feedback = true;                              // RTK_COST_FEEDBACK
-    unsigned resort_every = 8;                              // RTK_COST_RESORT_EVERY
+    unsigned resort_every = 16;                             // RTK_COST_RESORT_EVERY
     uint32_t light_cycles = 140000u;                        // RTK_LIGHT_BELOW_CYCLES
     uint32_t order_floor_cycles = 20000u;                   // RTK_ORDER_FLOOR_CYCLES
     bool batch_scalar_surv = false;                         // RTK_BATCH_SCALAR_SURV: the same in the batched intersect
