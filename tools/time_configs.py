@@ -10,6 +10,7 @@ CASES = {
     "cfg3 scene8 1080p spp1 d10": (f"{S}/hw11/scene8.crtscene", dict(width=1920, height=1080, spp=1, max_ray_depth=10)),
     "cfg3 scene8 1080p spp4 d10": (f"{S}/hw11/scene8.crtscene", dict(width=1920, height=1080, spp=4, max_ray_depth=10)),
     "cfg4 hw15s2 960 spp8 d5 gi1": (f"{S}/hw15/scene2.crtscene", dict(width=960, height=960, spp=8, max_ray_depth=5, diffuse_rays=1)),
+    "cfg5 hw15s2 4K spp4 d10 gi1": (f"{S}/hw15/scene2.crtscene", dict(width=3840, height=2160, spp=4, max_ray_depth=10, diffuse_rays=1)),
     "hw15s2 1920 spp1 d5": (f"{S}/hw15/scene2.crtscene", dict(width=1920, height=1920, spp=1, max_ray_depth=5)),
 }
 names = {0: "auto", 1: "lane", 2: "wave", 3: "group4", 6: "stream", 7: "twopass"}
