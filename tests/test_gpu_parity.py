@@ -251,6 +251,19 @@ def test_light_bursts_with_any_number_of_lights(rtk, ora, n_lights, tmp_path):
         assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref))
 
 
+@pytest.mark.parametrize("w,h", [(8, 8), (9, 7), (16, 8), (24, 24), (64, 64), (200, 120)])
+def test_tiny_frames_repeated_through_the_cost_feedback(rtk, ora, w, h):
+    """One pixel block, a ragged one, a handful: the block order / workgroup list machinery (k_order_by_cost: single-block and
+    packed workgroups merged by expected duration, refreshed every 16th frame) must cope with frames that have fewer blocks than a
+    workgroup has waves, and every repetition must keep the bits."""
+    acc, oacc = _scene_pair(rtk, ora, SCENE5)
+    ref, _ = oacc.render(w, h, 1, 5, 0)
+    for mode in ("auto", "group4", "group8"):
+        for i in range(36):
+            rgb, _ = acc.render_frame(rtk.RenderConfig(width=w, height=h, max_ray_depth=5, trace_mode=FRAME_MODES[mode]))
+            assert np.array_equal(_bits(rgb), _bits(ref)), (mode, i)
+
+
 @pytest.mark.parametrize("scene", list(CONFIG_SCENES))
 def test_render_gate_b_kd_tree_accel(rtk, ora, scene):
     """Gate B (BASELINE wording): normalize_hit_normal=0 vs the CPU kd_tree_accel render, |delta| < 1e-4."""
