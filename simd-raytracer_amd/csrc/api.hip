@@ -751,7 +751,8 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         rc = ensure_stream_ws(a, out_pixels, n_root * factor + 4096, a->scene.lights.size(), p->spp > 1, lanes);
         if (rc != RTK_OK) return rc;
         dev::StreamArgs S;
-        S.r = A; S.r.tree.scalar_surv = a->knobs.stream_scalar_surv ? 1 : 0; S.ws = a->ws; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root); S.auto_min_lanes = a->knobs.auto_min_lanes;
+        S.r = A; S.r.tree.scalar_surv = a->knobs.stream_scalar_surv ? 1 : 0; S.ws = a->ws;
+        S.key_dirs = p->diffuse_rays > 0 ? 1u : 0u; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root); S.auto_min_lanes = a->knobs.auto_min_lanes;
         S.n_lanes = uint32_t(lanes);
         for (int j = 0; j < dev::kStreamLanes; ++j) S.lane_overflow[j] = a->ws_lane[j < lanes ? j : 0].ctrl + dev::kCtrlOverflow;
         // measured on MI355X: the workgroup-cooperative wave walk beats the per-lane walk at every depth, even for the

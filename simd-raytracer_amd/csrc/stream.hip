@@ -139,9 +139,27 @@ __device__ __forceinline__ uint32_t grid_cell(const StreamArgs &S, const V3 p) {
     const uint32_t cz = fz > 0.f ? (fz < 15.f ? (uint32_t)fz : 15u) : 0u;
     return (cx << 8) | (cy << 4) | cz;
 }
+// 15 bits.  Frames without diffuse rays (key_dirs == 0): the origin's cell in a 16^3 grid over the scene and the
+// direction's octant -- reflections and refractions leave a surface patch in a few directions, position is what tells
+// them apart.  Frames with diffuse rays: an 8^3 origin grid and the direction's cell in a 4^3 grid over the L1-normalised
+// direction, interleaved from the most significant bit down (p2 d1 p1 d0 p0 per axis triple) -- diffuse rays leave one cell in
+// every direction of an octant, and made wide bundles (config 4's shape -6 %, config 5's -9 %; on the refractive dragon of
+// config 3 the coarser origin grid costs 4 %, hence the switch).
 __device__ __forceinline__ uint32_t ray_sort_key(const StreamArgs &S, const V3 o, const V3 d) {
-    const uint32_t octant = (d.x > 0.f ? 1u : 0u) | (d.y > 0.f ? 2u : 0u) | (d.z > 0.f ? 4u : 0u);
-    return (octant << 12) | grid_cell(S, o);
+    if (S.key_dirs == 0u) {
+        const uint32_t octant = (d.x > 0.f ? 1u : 0u) | (d.y > 0.f ? 2u : 0u) | (d.z > 0.f ? 4u : 0u);
+        return (octant << 12) | grid_cell(S, o);
+    }
+    const uint32_t c = grid_cell(S, o);                                     // 4 bits per axis; the top 3 are used
+    const uint32_t px = (c >> 9) & 7u, py = (c >> 5) & 7u, pz = (c >> 1) & 7u;
+    const float l1 = (__builtin_fabsf(d.x) + __builtin_fabsf(d.y)) + __builtin_fabsf(d.z);
+    const float k = l1 > 0.f ? 2.0f / l1 : 0.f;
+    const float fx = d.x * k + 2.0f, fy = d.y * k + 2.0f, fz = d.z * k + 2.0f;     // [0, 4]
+    const uint32_t dx = fx > 0.f ? (fx < 3.f ? (uint32_t)fx : 3u) : 0u;          // NaN compares false -> cell 0
+    const uint32_t dy = fy > 0.f ? (fy < 3.f ? (uint32_t)fy : 3u) : 0u;
+    const uint32_t dz = fz > 0.f ? (fz < 3.f ? (uint32_t)fz : 3u) : 0u;
+    auto tri = [](uint32_t a, uint32_t b, uint32_t cc, uint32_t bit) { return (((a >> bit) & 1u) << 2) | (((b >> bit) & 1u) << 1) | ((cc >> bit) & 1u); };
+    return (tri(px, py, pz, 2u) << 12) | (tri(dx, dy, dz, 1u) << 9) | (tri(px, py, pz, 1u) << 6) | (tri(dx, dy, dz, 0u) << 3) | tri(px, py, pz, 0u);
 }
 
 __device__ __forceinline__ void store_ray(RayRec *dst, const V3 o, const V3 d, const uint32_t parent, const uint32_t pixel,
@@ -438,22 +456,31 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
 // ------------------------------------------------------------------------------------------------
 // Counting sort of a level's rays / shading points (see kSortBins): k_path filled the histogram while appending;
 // k_sort_scan turns it into start offsets, k_sort_scatter_* hands every record a slot.
-__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t *bins) {
-    __shared__ uint32_t part[1024];
-    constexpr uint32_t per = kSortBins / 1024u;
-    uint32_t local[per];
+// (256 threads, not 1,024: the kernel is one workgroup in the middle of a level's dependency chain, and while the other
+// samples' kernels fill the chip a 16-wave workgroup waits for a CU to drain -- 563 us on average on config 4's shape, against
+// 15 us of work; a 4-wave one takes the next free slot.)
+__global__ __launch_bounds__(256) void k_sort_scan(uint32_t *bins) {
+    __shared__ uint32_t part[256];
+    constexpr uint32_t per = kSortBins / 256u;
+    static_assert(kSortBins % (256u * 4u) == 0u, "k_sort_scan reads four bins at a time");
+    uint4 *b4 = reinterpret_cast<uint4 *>(bins + threadIdx.x * per);
     uint32_t sum = 0;
-    for (uint32_t i = 0; i < per; ++i) { local[i] = bins[threadIdx.x * per + i]; sum += local[i]; }
+    for (uint32_t i = 0; i < per / 4u; ++i) { const uint4 v = b4[i]; sum += (v.x + v.y) + (v.z + v.w); }
     part[threadIdx.x] = sum;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+    for (uint32_t off = 1; off < 256u; off <<= 1) {
         const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
         __syncthreads();
         part[threadIdx.x] += v;
         __syncthreads();
     }
     uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t i = 0; i < per; ++i) { bins[threadIdx.x * per + i] = run; run += local[i]; }
+    for (uint32_t i = 0; i < per / 4u; ++i) {
+        const uint4 v = b4[i];
+        uint4 o;
+        o.x = run; run += v.x; o.y = run; run += v.y; o.z = run; run += v.z; o.w = run; run += v.w;
+        b4[i] = o;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sort_scatter_nodes(StreamArgs S) {
@@ -607,7 +634,7 @@ hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int dee
         else launch_path<false, 1, RTK_TRACE_AUTO>(S, stats, wave_units, s);
         if (level < A.max_depth && A.n_lights > 0) {
             if (S.hits_sorted) {
-                hipLaunchKernelGGL(dev::k_sort_scan, dim3(1), dim3(1024), 0, s, S.ws.hit_bins);
+                hipLaunchKernelGGL(dev::k_sort_scan, dim3(1), dim3(256), 0, s, S.ws.hit_bins);
                 hipLaunchKernelGGL(dev::k_sort_scatter_hits, dim3(1024), dim3(256), 0, s, S);
                 e = hipMemsetAsync(S.ws.hit_bins, 0, dev::kSortBins * sizeof(uint32_t), s);
                 if (e != hipSuccess) return e;
@@ -629,7 +656,7 @@ hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int dee
         if (S.bin_children) {                                  // order the next level's rays
             dev::StreamArgs N = S;
             N.level = (uint32_t)level + 1u;
-            hipLaunchKernelGGL(dev::k_sort_scan, dim3(1), dim3(1024), 0, s, S.ws.node_bins);
+            hipLaunchKernelGGL(dev::k_sort_scan, dim3(1), dim3(256), 0, s, S.ws.node_bins);
             hipLaunchKernelGGL(dev::k_sort_scatter_nodes, dim3(1024), dim3(256), 0, s, N);
             e = hipMemsetAsync(S.ws.node_bins, 0, dev::kSortBins * sizeof(uint32_t), s);
             if (e != hipSuccess) return e;

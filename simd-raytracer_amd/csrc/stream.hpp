@@ -91,6 +91,7 @@ struct StreamArgs {
     uint32_t hits_sorted;    // k_shadow: this level's shading points are taken through ws.hit_order
     uint32_t bin_children;   // k_path: histogram the rays it spawns (the next level will be sorted)
     uint32_t bin_hits;       // k_path: histogram the shading points it appends
+    uint32_t key_dirs;       // ray_sort_key: 1 = spend six of the fifteen key bits on the direction (frames with diffuse rays)
     float grid_lo[3], grid_scale[3];   // cell = clamp((p - lo) * scale, 0, 15)
 };
 
