@@ -32,6 +32,16 @@ def test_abi_version_and_struct_sizes(rtk):
     assert ctypes.sizeof(rtk.RenderParams) == 72        # 64 + sample_begin, sample_count (ABI 3)
 
 
+def test_trace_mode_constants_match_the_header(rtk):
+    """The Python mirror's TRACE_* constants are the RTK_TRACE_* enumerators of include/rtk.h, one for one."""
+    text = open(os.path.join(ROOT, "include", "rtk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    header = {name: int(value) for name, value in re.findall(r"\bRTK_TRACE_([A-Z0-9]+)\s*=\s*(\d+)", text)}
+    assert len(header) == 9 and header["REPACK"] == 8
+    mirror = {k[len("TRACE_"):]: v for k, v in vars(rtk).items() if k.startswith("TRACE_") and isinstance(v, int)}
+    assert mirror == header
+
+
 def test_device_count_is_reported_without_a_gpu(rtk):
     assert rtk.device_count() >= 0
 
