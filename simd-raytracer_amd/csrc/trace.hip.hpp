@@ -314,7 +314,8 @@ constexpr uint32_t kBundleMinTris = 4;   // leaves (or slices) smaller than this
 #define RTK_SPLIT_LEVELS 1
 #endif
 constexpr int kMaxBundles = 4;
-constexpr int kBundleSplitLevels = RTK_SPLIT_LEVELS;   // 1: a wide class is cut in two; 2: and its halves once more
+constexpr int kBundleSplitLevels = RTK_SPLIT_LEVELS;   // 1: a wide class is cut in two; 2: and its halves once more (measured:
+                                                       // config 2 unchanged, the diffuse-ray frames of configs 4 / 5 4-6 % slower)
 constexpr float kBundleSplitRadius = 0.03f;   // a pencil whose direction box is wider than this (per axis, half width) is cut in two
 constexpr int kBundleFloats = 40;       // see make_bundles for the layout
 constexpr uint32_t kClsHasApex = 0x80000000u;   // bit of the caller's ray class: the `apex` passed along is meaningful
