@@ -483,16 +483,40 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t *bins) {
     }
 }
 
+// A record's slot in its bin: one returning atomic per record is what these kernels spend their time on (the records of a
+// level arrive in the order their parents were processed, so the lanes of a wave mostly want the same few bins, and a
+// returning atomic on one address is a ~1 us round trip that the others queue behind).  The lanes that share the first
+// pending lane's bin are served by ONE atomic, for up to four bins; whoever is left after that takes its own.
+__device__ __forceinline__ uint32_t bin_slot(uint32_t *bins, const uint32_t key, const bool have) {
+    const uint32_t lane = __lane_id();
+    unsigned long long rem = __builtin_amdgcn_ballot_w64(have);
+    uint32_t slot = 0xFFFFFFFFu;
+    for (int round = 0; round < 4 && rem != 0ull; ++round) {
+        const int leader = __builtin_ctzll(rem);
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(have && key == k0) & rem;
+        uint32_t first = 0u;
+        if ((int)lane == leader) first = atomicAdd(bins + k0, (uint32_t)__popcll(same));
+        first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+        if ((same >> lane) & 1ull) slot = first + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        rem &= ~same;
+    }
+    if ((rem >> lane) & 1ull) slot = atomicAdd(bins + key, 1u);
+    return slot;
+}
+
 __global__ __launch_bounds__(256) void k_sort_scatter_nodes(StreamArgs S) {
     if (S.ws.ctrl[kCtrlOverflow] != 0u) return;
     uint32_t base, count;
     level_range(S.ws.ctrl + kCtrlNodeCount, S.n_root, S.level, S.ws.node_cap, base, count);
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const float4 *q = reinterpret_cast<const float4 *>(S.ws.rays + base + i);
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < count; i0 += stride) {           // (whole waves stay in the loop: bin_slot is wave-wide)
+        const uint32_t i = i0 + threadIdx.x;
+        const bool have = i < count;
+        const float4 *q = reinterpret_cast<const float4 *>(S.ws.rays + base + (have ? i : 0u));
         const float4 a = q[0], b = q[1];
-        const uint32_t slot = atomicAdd(S.ws.node_bins + ray_sort_key(S, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z)), 1u);
-        if (slot < count) S.ws.node_order[slot] = base + i;
+        const uint32_t slot = bin_slot(S.ws.node_bins, ray_sort_key(S, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z)), have);
+        if (have && slot < count) S.ws.node_order[slot] = base + i;
     }
 }
 
@@ -505,10 +529,12 @@ __global__ __launch_bounds__(256) void k_sort_scatter_hits(StreamArgs S) {
     const uint32_t hit_base = hb < S.ws.hit_cap ? (uint32_t)hb : S.ws.hit_cap;
     const uint32_t n_hits = (hb + hc <= S.ws.hit_cap) ? (uint32_t)hc : S.ws.hit_cap - hit_base;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += stride) {
-        const float4 a = *reinterpret_cast<const float4 *>(S.ws.hits + hit_base + i);
-        const uint32_t slot = atomicAdd(S.ws.hit_bins + grid_cell(S, mk(a.x, a.y, a.z)), 1u);
-        if (slot < n_hits) S.ws.hit_order[hit_base + slot] = hit_base + i;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n_hits; i0 += stride) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool have = i < n_hits;
+        const float4 a = *reinterpret_cast<const float4 *>(S.ws.hits + hit_base + (have ? i : 0u));
+        const uint32_t slot = bin_slot(S.ws.hit_bins, grid_cell(S, mk(a.x, a.y, a.z)), have);
+        if (have && slot < n_hits) S.ws.hit_order[hit_base + slot] = hit_base + i;
     }
 }
 
