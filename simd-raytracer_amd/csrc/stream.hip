@@ -71,6 +71,21 @@ __device__ __forceinline__ uint32_t wave_append_1(uint32_t *counter, const bool 
     return start + lane_prefix(mask);
 }
 
+// Histogram count, one atomic per wave and bin for the first few bins the lanes want (see bin_slot): wave-wide, call it from
+// converged code with `want` as the predicate.
+__device__ __forceinline__ void bin_count(uint32_t *bins, const uint32_t key, const bool want) {
+    const uint32_t lane = __lane_id();
+    unsigned long long rem = __builtin_amdgcn_ballot_w64(want);
+    for (int round = 0; round < 4 && rem != 0ull; ++round) {
+        const int leader = __builtin_ctzll(rem);
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(want && key == k0) & rem;
+        if ((int)lane == leader) atomicAdd(bins + k0, (uint32_t)__popcll(same));
+        rem &= ~same;
+    }
+    if ((rem >> lane) & 1ull) atomicAdd(bins + key, 1u);
+}
+
 // Dynamic work distribution for the queue-driven stages: a unit's first item is its own index, every further item
 // is drawn from an atomic ticket, so the stage ends when the queue is empty rather than when the unluckiest static
 // share is done.
@@ -312,19 +327,22 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
         const uint32_t hit_slot = wave_append_1(ctrl + kCtrlHitCount + level, push_hit, hit_base, S.ws.hit_cap, ctrl + kCtrlOverflow);
         if (child_slot == 0xFFFFFFFFu || hit_slot == 0xFFFFFFFFu) { kind = NODE_LEAF; nchild = 0u; push_hit = false; child_slot = 0u; }
         const uint32_t first_child = next_base + child_slot;
-        if (kind == NODE_PASS || kind == NODE_REFR) {
+        const bool spawn01 = kind == NODE_PASS || kind == NODE_REFR;
+        if (spawn01) {
             store_ray(S.ws.rays + first_child, c0o, c0d, node, pix, child_key(key, 0u), kRayValid | (c0_bg ? kRayMissBackground : 0u));
-            if (S.bin_children) atomicAdd(S.ws.node_bins + ray_sort_key(S, c0o, c0d), 1u);
-            if (kind == NODE_REFR) {
-                store_ray(S.ws.rays + first_child + 1u, c1o, c1d, node, pix, child_key(key, 1u), kRayValid);
-                if (S.bin_children) atomicAdd(S.ws.node_bins + ray_sort_key(S, c1o, c1d), 1u);
-            }
-        } else if (kind == NODE_DIFF || kind == NODE_TEX) {
+            if (kind == NODE_REFR) store_ray(S.ws.rays + first_child + 1u, c1o, c1d, node, pix, child_key(key, 1u), kRayValid);
+        }
+        if (S.bin_children) {                                                                   // (wave-wide: bin_count)
+            bin_count(S.ws.node_bins, ray_sort_key(S, c0o, c0d), spawn01);
+            bin_count(S.ws.node_bins, ray_sort_key(S, c1o, c1d), kind == NODE_REFR);
+        }
+        const bool shade_point = kind == NODE_DIFF || kind == NODE_TEX;
+        if (S.bin_hits) bin_count(S.ws.hit_bins, grid_cell(S, P), shade_point);
+        if (shade_point) {
             aux = hit_base + hit_slot;
             float4 *q = reinterpret_cast<float4 *>(S.ws.hits + aux);
             q[0] = make_float4(P.x, P.y, P.z, __uint_as_float(node));
             q[1] = make_float4(ncos.x, ncos.y, ncos.z, __uint_as_float(mat));
-            if (S.bin_hits) atomicAdd(S.ws.hit_bins + grid_cell(S, P), 1u);
             for (uint32_t gi = 0; gi < nchild; ++gi) {                                          // GI rays, :151-176
                 const V3 right = normalized(cross(ray.d, hn));
                 const V3 up = hn;
