@@ -343,7 +343,12 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
             float4 *q = reinterpret_cast<float4 *>(S.ws.hits + aux);
             q[0] = make_float4(P.x, P.y, P.z, __uint_as_float(node));
             q[1] = make_float4(ncos.x, ncos.y, ncos.z, __uint_as_float(mat));
-            for (uint32_t gi = 0; gi < nchild; ++gi) {                                          // GI rays, :151-176
+        }
+        // GI rays, :151-176.  The loop runs wave-wide (diffuse_rays is uniform; `mine` says whose ray it is) so that the
+        // histogram of the spawned rays can be counted per wave (bin_count); a lane's arithmetic is what it was.
+        if (wave_any(shade_point && nchild != 0u)) {
+            for (uint32_t gi = 0; gi < (uint32_t)A.diffuse_rays; ++gi) {
+                const bool mine = shade_point && gi < nchild;
                 const V3 right = normalized(cross(ray.d, hn));
                 const V3 up = hn;
                 const V3 fwd = cross(right, up);
@@ -356,8 +361,8 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
                 const V3 org = P + (A.reflection_bias * hn);
                 const V3 dir = mk(right.x * rv.x + right.y * rv.y + right.z * rv.z, up.x * rv.x + up.y * rv.y + up.z * rv.z,
                                   fwd.x * rv.x + fwd.y * rv.y + fwd.z * rv.z);
-                store_ray(S.ws.rays + first_child + gi, org, dir, node, pix, child_key(key, gi), kRayValid);
-                if (S.bin_children) atomicAdd(S.ws.node_bins + ray_sort_key(S, org, dir), 1u);
+                if (mine) store_ray(S.ws.rays + first_child + gi, org, dir, node, pix, child_key(key, gi), kRayValid);
+                if (S.bin_children) bin_count(S.ws.node_bins, ray_sort_key(S, org, dir), mine);
             }
         }
         if (in_range) {
