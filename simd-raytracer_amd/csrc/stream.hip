@@ -89,6 +89,10 @@ __device__ __forceinline__ void bin_count(uint32_t *bins, const uint32_t key, co
 // Dynamic work distribution for the queue-driven stages: a unit's first item is its own index, every further item
 // is drawn from an atomic ticket, so the stage ends when the queue is empty rather than when the unluckiest static
 // share is done.
+#ifndef RTK_TICKET_ITEMS
+#define RTK_TICKET_ITEMS 4
+#endif
+constexpr uint32_t kTicketItems = RTK_TICKET_ITEMS;
 __device__ __forceinline__ uint32_t next_item(uint32_t *ticket, const uint32_t n_units) {
     uint32_t t = 0u;
     if (__lane_id() == 0u) t = atomicAdd(ticket, 1u);
@@ -235,7 +239,11 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     sx.rebundle = false;
     uint32_t nrays = 0;
 
-    for (uint32_t item = gunit; item < n_items; item = LEVEL0 ? n_items : next_item(ctrl + kCtrlTicket + level, n_units_grid)) {
+    // (a ticket is good for kTicketItems consecutive work units: the ticket word is one address every wave of the kernel pulls on)
+    // (only where there are many units per wave: a short queue is better spread over all waves, one unit each)
+    const uint32_t kPer = (!LEVEL0 && n_items >= 16u * n_units_grid) ? kTicketItems : 1u;
+    for (uint32_t tb = gunit; tb * kPer < n_items; tb = LEVEL0 ? n_items : next_item(ctrl + kCtrlTicket + level, n_units_grid))
+    for (uint32_t item = tb * kPer; item < n_items && item < (tb + 1u) * kPer; ++item) {
         const bool in_range = item * 64u + lane < count;
         uint32_t node = base + item * 64u + lane;
         if (!LEVEL0 && S.nodes_sorted) {
@@ -423,7 +431,9 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     sx.rebundle = false;
     uint32_t nrays = 0;
 
-    for (uint32_t item = gunit; item < n_items; item = next_item(ctrl + kCtrlTicket + kLevels + S.level, n_units_grid)) {
+    const uint32_t kPer = n_items >= 16u * n_units_grid ? kTicketItems : 1u;           // (see k_path)
+    for (uint32_t tb = gunit; tb * kPer < n_items; tb = next_item(ctrl + kCtrlTicket + kLevels + S.level, n_units_grid))
+    for (uint32_t item = tb * kPer; item < n_items && item < (tb + 1u) * kPer; ++item) {
         const uint32_t group = item / n_lights, k = item % n_lights;
         const uint32_t hl = group * 64u + lane;
         const bool valid = hl < n_hits;
