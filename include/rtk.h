@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTK_ABI_VERSION 3
+#define RTK_ABI_VERSION 4
 
 /* status codes (reference: intersect is noexcept, miss = nullopt, kd_tree_simd.hpp:188,231;
  * loader throws std::invalid_argument, io/json/loader.hpp:104,127,145,170,190,224) */
@@ -33,14 +33,16 @@ enum {
     RTK_ERR_HIP = 3,          /* a HIP runtime call failed */
     RTK_ERR_IO = 4,           /* file could not be read / written */
     RTK_ERR_PARSE = 5,        /* .crtscene is not valid JSON or misses a required key */
-    RTK_ERR_UNSUPPORTED = 6   /* feature outside the accelerated path (bitmap textures) */
+    RTK_ERR_UNSUPPORTED = 6   /* feature outside the accelerated path (bitmap texture files other than baseline JPEG) */
 };
 
 /* material kinds: scene/material/material.hpp:12 */
 enum { RTK_MAT_DIFFUSE = 0, RTK_MAT_REFLECTIVE = 1, RTK_MAT_REFRACTIVE = 2, RTK_MAT_CONSTANT = 3, RTK_MAT_TEXTURE = 4 };
 
-/* texture kinds: scene/texture/texture.hpp:13 (bitmap_texture needs an image decoder and is not supported) */
-enum { RTK_TEX_ALBEDO = 0, RTK_TEX_EDGES = 1, RTK_TEX_CHECKER = 2 };
+/* texture kinds: scene/texture/texture.hpp:13.  RTK_TEX_BITMAP = bitmap_texture (scene/texture/bitmap.hpp): the texels
+ * travel as the RGB bytes `stbi_load` returns (tex_pixels); rtk_scene_load_crtscene decodes baseline JPEG files itself
+ * (csrc/jpeg.cpp, stb_image's arithmetic) */
+enum { RTK_TEX_ALBEDO = 0, RTK_TEX_EDGES = 1, RTK_TEX_CHECKER = 2, RTK_TEX_BITMAP = 3 };
 
 /* traversal strategy of the device kernels; all of them give bit-identical results */
 enum {
@@ -100,6 +102,11 @@ typedef struct {
     float background[3];            /* settings::background_color */
     int32_t width, height;          /* settings::image_width/height */
     int32_t bucket_size;            /* settings::bucket_size (default 64, loader.hpp:48) */
+    /* bitmap_texture::texture (scene/texture/bitmap.hpp:11-44) of every RTK_TEX_BITMAP texture: 3 bytes per texel, rows top-down,
+     * as stbi_load returns them (bitmap.hpp turns a byte b into F(b) * F(1.0 / 255.0)); all textures concatenated.
+     * tex_bitmap[i] = {byte offset of texture i in tex_pixels, width, height}.  Both may be NULL without bitmap textures. */
+    const uint8_t *tex_pixels;
+    const int32_t *tex_bitmap;      /* [n_textures][3] */
 } rtk_scene_desc;
 
 typedef struct {
@@ -107,6 +114,7 @@ typedef struct {
     int32_t n_vertices, n_triangles;
     int32_t width, height, bucket_size;
     int32_t n_textures, n_uv_vertices;   /* n_uv_vertices = vertices of the meshes that carry uvs */
+    int32_t n_bitmap_bytes;              /* size of the concatenated texel bytes of all bitmap textures */
 } rtk_scene_info;
 
 /* template parameters of kd_tree_simd_accel (kd_tree_simd.hpp:63-67) as runtime values */
@@ -189,6 +197,12 @@ int rtk_scene_get_arrays(const rtk_scene *scene, int32_t *mesh_material, int32_t
 /* texture side of the scene: [n_materials], [n_meshes], [n_uv_vertices][2], [n_textures], [n_textures][3] x2, [n_textures] */
 int rtk_scene_get_textures(const rtk_scene *scene, int32_t *mat_texture, int32_t *mesh_has_uvs, float *uvs,
                            int32_t *tex_kind, float *tex_color_a, float *tex_color_b, float *tex_param);
+/* bitmap textures: tex_bitmap [n_textures][3] = {byte offset, width, height}, tex_pixels [n_bitmap_bytes]; either may be NULL */
+int rtk_scene_get_bitmaps(const rtk_scene *scene, int32_t *tex_bitmap, uint8_t *tex_pixels);
+/* The decoder behind bitmap textures: what `stbi_load(path, &w, &h, &channels, 0)` (scene/texture/bitmap.hpp:15) returns for a
+ * baseline JPEG held in memory.  *channels = 1 or 3; writes at most cap bytes (pixels may be NULL to query the size). */
+int rtk_decode_jpeg(const uint8_t *data, size_t size, int32_t *width, int32_t *height, int32_t *channels,
+                    uint8_t *pixels, size_t cap);
 /* mesh_object::vertex_normals (scene/object/mesh.hpp:25-43), [nverts of that mesh][3] */
 int rtk_scene_vertex_normals(const rtk_scene *scene, int32_t mesh, float *out);
 void rtk_scene_destroy(rtk_scene *scene);

@@ -3,8 +3,9 @@
 TEST INFRASTRUCTURE ONLY.  Allowed importers: tests/, __graft_entry__.smoke(), and the
 cpu_baseline leg of bench.py.  The product package (simd-raytracer_amd/) never imports this.
 
-Parity-pin status: see oracle/rt_oracle.h — pinned by reference-measured counters recorded in
-SURVEY.md, per-pixel parity against a reference binary is "parity unpinned".
+Parity-pin status: see oracle/rt_oracle.h — pinned by the reference's own committed renders
+(tests/golden/ref_outputs/, every byte of refractive_dragon.png and textures.png) and by the
+reference-measured counters recorded in SURVEY.md.
 """
 from __future__ import annotations
 
@@ -19,7 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 MAT_DIFFUSE, MAT_REFLECTIVE, MAT_REFRACTIVE, MAT_CONSTANT, MAT_TEXTURE = 0, 1, 2, 3, 4
-TEX_ALBEDO, TEX_EDGES, TEX_CHECKER = 0, 1, 2
+TEX_ALBEDO, TEX_EDGES, TEX_CHECKER, TEX_BITMAP = 0, 1, 2, 3
 ACCEL_KD_SIMD, ACCEL_KD_SCALAR = 0, 1
 C_RAYS, C_HITS, C_NODES, C_BOXPASS, C_LEAVES, C_PACKETS, C_TRIS, C_PRIMARY, C_COUNT = range(9)
 COUNTER_NAMES = ["rays", "hits", "nodes", "boxpass", "leaves", "packets", "tris", "primary"]
@@ -84,6 +85,8 @@ class _SceneDesc(C.Structure):
         ("width", C.c_int32),
         ("height", C.c_int32),
         ("bucket_size", C.c_int32),
+        ("tex_pixels", C.POINTER(C.c_uint8)),
+        ("tex_bitmap", C.POINTER(C.c_int32)),
     ]
 
 
@@ -183,16 +186,43 @@ class FlatScene:
     tex_color_a: np.ndarray = None
     tex_color_b: np.ndarray = None
     tex_param: np.ndarray = None
+    tex_pixels: np.ndarray = None     # uint8, the decoded RGB bytes of all bitmap textures, concatenated
+    tex_bitmap: np.ndarray = None     # [n_textures, 3] int32: byte offset into tex_pixels, width, height
     extra: dict = field(default_factory=dict)
 
 
-def load_crtscene(path: str) -> FlatScene:
-    """Independent Python reader for .crtscene (used only to feed the oracle)."""
+def resolve_texture_path(scene_path: str, file_path: str) -> str:
+    """The reference opens `file_path` relative to the process's working directory, which its README asks to be the project
+    root (README.md:32-35).  Here: as given if it exists, else below the nearest ancestor of the scene file that holds it."""
+    if os.path.exists(file_path):
+        return file_path
+    d = os.path.dirname(os.path.abspath(scene_path))
+    while True:
+        cand = os.path.join(d, file_path)
+        if os.path.exists(cand):
+            return cand
+        # the fixtures keep the reference's scenes/ tree without its project root: scenes/hw12/textures/x.jpg -> hw12/textures/x.jpg
+        parts = file_path.replace("\\", "/").split("/")
+        for k in range(1, len(parts)):
+            cand = os.path.join(d, *parts[k:])
+            if os.path.exists(cand):
+                return cand
+        nd = os.path.dirname(d)
+        if nd == d:
+            raise FileNotFoundError(file_path)
+        d = nd
+
+
+def load_crtscene(path: str, bitmaps: bool = True) -> FlatScene:
+    """Independent Python reader for .crtscene (used only to feed the oracle).
+
+    bitmaps=False: a bitmap texture raises NotImplementedError instead of being decoded (oracle/stb_jpeg.py)."""
     with open(path) as f:
         doc = json.load(f)
     st = doc["settings"]
     img = st["image_settings"]
     tex_names, tkind, ta, tb, tp, tbitmap = [], [], [], [], [], []
+    tpix, tbmp = [], []
     for t in doc.get("textures", []) if isinstance(doc.get("textures", []), list) else []:      # loader.hpp:78-106
         ty = t["type"]
         tex_names.append(t["name"])
@@ -203,10 +233,19 @@ def load_crtscene(path: str) -> FlatScene:
             tkind.append(TEX_EDGES); ta.append(t["edge_color"][:3]); tb.append(t["inner_color"][:3]); tp.append(t["edge_width"])
         elif ty == "checker":
             tkind.append(TEX_CHECKER); ta.append(t["color_A"][:3]); tb.append(t["color_B"][:3]); tp.append(t["square_size"])
-        elif ty == "bitmap":
-            tkind.append(TEX_ALBEDO); ta.append([0, 0, 0]); tb.append([0, 0, 0]); tp.append(0.0)
+        elif ty == "bitmap":                                              # loader.hpp:97-101, texture/bitmap.hpp:11-37
+            tkind.append(TEX_BITMAP); ta.append([0, 0, 0]); tb.append([0, 0, 0]); tp.append(0.0)
         else:
             raise ValueError("texture type unknown")  # loader.hpp:104
+        if ty == "bitmap" and bitmaps:
+            from . import stb_jpeg
+            px = stb_jpeg.load(resolve_texture_path(path, t["file_path"]))
+            if px.shape[2] != 3:
+                raise NotImplementedError("bitmap.hpp:26-28 reads three channels per pixel")
+            tbmp.append([sum(len(x) for x in tpix), px.shape[1], px.shape[0]])
+            tpix.append(px.reshape(-1))
+        else:
+            tbmp.append([0, 0, 0])
     mats = doc["materials"]
     kinds, alb, ior, smooth, mtex = [], [], [], [], []
     for m in mats:
@@ -216,8 +255,8 @@ def load_crtscene(path: str) -> FlatScene:
         tex = -1
         if t == "diffuse" and isinstance(m["albedo"], str):          # texture_material, loader.hpp:120-125
             tex = tex_names.index(m["albedo"])
-            if tbitmap[tex]:
-                raise NotImplementedError("bitmap textures need an image decoder (SURVEY.md §8f)")
+            if tbitmap[tex] and not bitmaps:
+                raise NotImplementedError("bitmap texture (decode with bitmaps=True)")
             kinds.append(MAT_TEXTURE)
             alb.append([0, 0, 0])
         else:
@@ -273,6 +312,8 @@ def load_crtscene(path: str) -> FlatScene:
         tex_color_a=np.asarray(ta, np.float64).astype(np.float32).reshape(-1, 3),
         tex_color_b=np.asarray(tb, np.float64).astype(np.float32).reshape(-1, 3),
         tex_param=np.asarray(tp, np.float64).astype(np.float32),
+        tex_pixels=np.ascontiguousarray(np.concatenate(tpix) if tpix else np.zeros(0, np.uint8)),
+        tex_bitmap=np.asarray(tbmp, np.int32).reshape(-1, 3),
     )
 
 
@@ -305,12 +346,15 @@ class Scene:
             ta=flat.tex_color_a if flat.tex_color_a is not None else np.zeros((0, 3), np.float32),
             tb=flat.tex_color_b if flat.tex_color_b is not None else np.zeros((0, 3), np.float32),
             tp=flat.tex_param if flat.tex_param is not None else np.zeros(0, np.float32),
+            px=flat.tex_pixels if flat.tex_pixels is not None else np.zeros(0, np.uint8),
+            bm=flat.tex_bitmap if flat.tex_bitmap is not None else np.zeros((len(flat.tex_kind) if flat.tex_kind is not None else 0, 3), np.int32),
         )
         self._tex = {k: np.ascontiguousarray(v) for k, v in self._tex.items()}
         d.mat_texture, d.uvs, d.mesh_has_uvs = _p(self._tex["mt"], C.c_int32), _p(self._tex["uv"], C.c_float), _p(self._tex["hu"], C.c_int32)
         d.n_textures = len(self._tex["tk"])
         d.tex_kind, d.tex_color_a = _p(self._tex["tk"], C.c_int32), _p(self._tex["ta"], C.c_float)
         d.tex_color_b, d.tex_param = _p(self._tex["tb"], C.c_float), _p(self._tex["tp"], C.c_float)
+        d.tex_pixels, d.tex_bitmap = _p(self._tex["px"], C.c_uint8), _p(self._tex["bm"], C.c_int32)
         d.n_lights = len(flat.light_intensity)
         d.light_pos = _p(flat.light_pos, C.c_float)
         d.light_intensity = _p(flat.light_intensity, C.c_float)

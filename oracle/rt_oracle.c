@@ -120,7 +120,8 @@ typedef struct {                                /* scene/object/mesh.hpp:15-44 *
 } mesh_object;
 
 typedef struct { int32_t kind; float albedo[3]; float ior; int32_t smooth; int32_t texture; } material;
-typedef struct { int32_t kind; float a[3], b[3]; float param; } texture;   /* scene/texture/{albedo,edge,checker}.hpp */
+typedef struct { int32_t kind; float a[3], b[3]; float param;             /* scene/texture/{albedo,edge,checker}.hpp */
+                 int32_t bw, bh; uint8_t *pixels; } texture;              /* bitmap.hpp:40-44: image<F> as its RGB bytes */
 typedef struct { v3 position; float intensity; } light;
 
 struct ora_scene {
@@ -200,6 +201,13 @@ ora_scene *ora_scene_create(const ora_scene_desc *d) {
         memcpy(s->textures[i].a, &d->tex_color_a[i * 3], sizeof(float) * 3);
         memcpy(s->textures[i].b, &d->tex_color_b[i * 3], sizeof(float) * 3);
         s->textures[i].param = d->tex_param[i];
+        if (d->tex_kind[i] == ORA_TEX_BITMAP) {                             /* load_bitmap, bitmap.hpp:11-37 (decoded by the caller) */
+            const int32_t *b = &d->tex_bitmap[i * 3];
+            const size_t n = (size_t)b[1] * (size_t)b[2] * 3;
+            s->textures[i].bw = b[1]; s->textures[i].bh = b[2];
+            s->textures[i].pixels = (uint8_t *)malloc(n ? n : 1);
+            memcpy(s->textures[i].pixels, d->tex_pixels + b[0], n);
+        }
     }
     s->n_lights = d->n_lights;
     s->lights = (light *)calloc((size_t)(d->n_lights ? d->n_lights : 1), sizeof(light));
@@ -219,6 +227,7 @@ void ora_scene_destroy(ora_scene *s) {
     for (int m = 0; m < s->n_meshes; ++m) {
         free(s->meshes[m].vertices); free(s->meshes[m].vertex_normals); free(s->meshes[m].triangles);
     }
+    for (int i = 0; i < s->n_textures; ++i) free(s->textures[i].pixels);
     free(s->meshes); free(s->materials); free(s->textures); free(s->lights); free(s);
 }
 
@@ -686,6 +695,18 @@ static col sample_texture(const texture *t, const hit_rec *h) {
     if (t->kind == ORA_TEX_EDGES) return (hit_u < t->param || hit_v < t->param || hit_w < t->param) ? a : b;
     const float fx = (hit_w * h->uvs[0] + hit_u * h->uvs[2]) + hit_v * h->uvs[4];
     const float fy = (hit_w * h->uvs[1] + hit_u * h->uvs[3]) + hit_v * h->uvs[5];
+    if (t->kind == ORA_TEX_BITMAP) {                                        /* bitmap.hpp:46-59 */
+        /* `(1. - final_uv.y) * height`: double; `final_uv.x * width`: float (size_t converts to F); both truncate into a
+         * size_t.  A negative value is undefined there; x86-64 gives 0 above -1 and a huge value below, modelled here. */
+        const double rd = (1. - (double)fy) * (double)(size_t)t->bh;
+        const float cf = fx * (float)(size_t)t->bw;
+        const int64_t ri = (int64_t)rd, ci = (int64_t)cf;
+        const size_t row = ri < 0 || (size_t)ri > (size_t)t->bh - 1 ? (size_t)t->bh - 1 : (size_t)ri;
+        const size_t column = ci < 0 || (size_t)ci > (size_t)t->bw - 1 ? (size_t)t->bw - 1 : (size_t)ci;
+        const uint8_t *px = &t->pixels[(row * (size_t)t->bw + column) * 3];
+        const float color_scale = (float)(1.0 / 255.0);                     /* bitmap.hpp:19 */
+        return mkcol((float)px[0] * color_scale, (float)px[1] * color_scale, (float)px[2] * color_scale);
+    }
     const int32_t u2 = (int32_t)(fx / t->param), v2 = (int32_t)(fy / t->param);
     return ((u2 + v2) % 2 == 0) ? a : b;
 }

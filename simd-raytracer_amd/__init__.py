@@ -24,7 +24,7 @@ _LIB_PATH = os.environ.get("RTK_LIB_OVERRIDE") or os.path.join(_HERE, "librtk_hi
 
 RTK_OK, RTK_ERR_INVALID, RTK_ERR_NO_DEVICE, RTK_ERR_HIP, RTK_ERR_IO, RTK_ERR_PARSE, RTK_ERR_UNSUPPORTED = range(7)
 MAT_DIFFUSE, MAT_REFLECTIVE, MAT_REFRACTIVE, MAT_CONSTANT, MAT_TEXTURE = 0, 1, 2, 3, 4
-TEX_ALBEDO, TEX_EDGES, TEX_CHECKER = 0, 1, 2
+TEX_ALBEDO, TEX_EDGES, TEX_CHECKER, TEX_BITMAP = 0, 1, 2, 3
 TRACE_AUTO, TRACE_LANE, TRACE_WAVE, TRACE_GROUP4, TRACE_GROUP8, TRACE_GROUP16, TRACE_STREAM, TRACE_TWOPASS = 0, 1, 2, 3, 4, 5, 6, 7
 TRACE_REPACK = 8        # batched intersect only: rays sorted by origin / direction cell before the trace (csrc/repack.hip)
 
@@ -32,6 +32,7 @@ TRACE_REPACK = 8        # batched intersect only: rays sorted by origin / direct
 ABI_SYMBOLS = [
     "rtk_abi_version", "rtk_last_error", "rtk_device_count",
     "rtk_scene_create", "rtk_scene_load_crtscene", "rtk_scene_get_info", "rtk_scene_get_arrays", "rtk_scene_get_textures",
+    "rtk_scene_get_bitmaps", "rtk_decode_jpeg",
     "rtk_scene_vertex_normals", "rtk_scene_destroy",
     "rtk_accel_build", "rtk_accel_tree_info", "rtk_accel_tree_dump", "rtk_accel_destroy",
     "rtk_accel_intersect", "rtk_accel_intersect_device", "rtk_accel_intersect_stats",
@@ -78,13 +79,14 @@ class SceneDesc(C.Structure):
         ("n_lights", C.c_int32), ("light_pos", C.POINTER(C.c_float)), ("light_intensity", C.POINTER(C.c_float)),
         ("cam_pos", C.c_float * 3), ("cam_mat", C.c_float * 9), ("background", C.c_float * 3),
         ("width", C.c_int32), ("height", C.c_int32), ("bucket_size", C.c_int32),
+        ("tex_pixels", C.POINTER(C.c_uint8)), ("tex_bitmap", C.POINTER(C.c_int32)),
     ]
 
 
 class SceneInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n_meshes", "n_materials", "n_lights", "n_vertices", "n_triangles", "width", "height", "bucket_size",
-                 "n_textures", "n_uv_vertices")]
+                 "n_textures", "n_uv_vertices", "n_bitmap_bytes")]
 
 
 class AccelParams(C.Structure):
@@ -125,6 +127,8 @@ _L.rtk_scene_load_crtscene.argtypes = [C.c_char_p, C.POINTER(_vp)]
 _L.rtk_scene_get_info.argtypes = [_vp, C.POINTER(SceneInfo)]
 _L.rtk_scene_get_arrays.argtypes = [_vp] * 15
 _L.rtk_scene_get_textures.argtypes = [_vp] * 8
+_L.rtk_scene_get_bitmaps.argtypes = [_vp] * 3
+_L.rtk_decode_jpeg.argtypes = [_vp, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _vp, C.c_size_t]
 _L.rtk_scene_vertex_normals.argtypes = [_vp, C.c_int32, _vp]
 _L.rtk_scene_destroy.argtypes = [_vp]
 _L.rtk_scene_destroy.restype = None
@@ -190,7 +194,7 @@ class Scene:
     def from_arrays(cls, mesh_material, mesh_nverts, mesh_ntris, vertices, indices, mat_kind, mat_albedo, mat_ior,
                     mat_smooth, light_pos, light_intensity, cam_pos, cam_mat, background, width, height, bucket_size=64,
                     mat_texture=None, uvs=None, mesh_has_uvs=None, tex_kind=None, tex_color_a=None, tex_color_b=None,
-                    tex_param=None):
+                    tex_param=None, tex_pixels=None, tex_bitmap=None):
         n_tex = 0 if tex_kind is None else len(tex_kind)
         keep = dict(
             mt=np.ascontiguousarray(mat_texture if mat_texture is not None else np.full(len(mat_kind), -1), np.int32),
@@ -200,6 +204,8 @@ class Scene:
             ta=np.ascontiguousarray(tex_color_a if tex_color_a is not None else np.zeros((n_tex, 3)), np.float32),
             tb=np.ascontiguousarray(tex_color_b if tex_color_b is not None else np.zeros((n_tex, 3)), np.float32),
             tp=np.ascontiguousarray(tex_param if tex_param is not None else np.zeros(n_tex), np.float32),
+            px=np.ascontiguousarray(tex_pixels if tex_pixels is not None else np.zeros(0), np.uint8),
+            bm=np.ascontiguousarray(tex_bitmap if tex_bitmap is not None else np.zeros((n_tex, 3)), np.int32),
             mm=np.ascontiguousarray(mesh_material, np.int32), nv=np.ascontiguousarray(mesh_nverts, np.int32),
             nt=np.ascontiguousarray(mesh_ntris, np.int32), v=np.ascontiguousarray(vertices, np.float32),
             ix=np.ascontiguousarray(indices, np.uint32), mk=np.ascontiguousarray(mat_kind, np.int32),
@@ -218,6 +224,7 @@ class Scene:
         d.n_textures = n_tex
         d.tex_kind, d.tex_color_a = _fp(keep["tk"], C.c_int32), _fp(keep["ta"], C.c_float)
         d.tex_color_b, d.tex_param = _fp(keep["tb"], C.c_float), _fp(keep["tp"], C.c_float)
+        d.tex_pixels, d.tex_bitmap = _fp(keep["px"], C.c_uint8), _fp(keep["bm"], C.c_int32)
         d.n_lights = len(keep["li"])
         d.light_pos, d.light_intensity = _fp(keep["lp"], C.c_float), _fp(keep["li"], C.c_float)
         d.cam_pos[:] = [float(x) for x in np.asarray(cam_pos, np.float32)]
@@ -248,6 +255,9 @@ class Scene:
         )
         _check(_L.rtk_scene_get_textures(self._h, *[a.ctypes.data for a in tex.values()]))
         out.update(tex)
+        bmp = dict(tex_bitmap=np.zeros((i.n_textures, 3), np.int32), tex_pixels=np.zeros(i.n_bitmap_bytes, np.uint8))
+        _check(_L.rtk_scene_get_bitmaps(self._h, bmp["tex_bitmap"].ctypes.data, bmp["tex_pixels"].ctypes.data))
+        out.update(bmp)
         out.update(width=i.width, height=i.height, bucket_size=i.bucket_size)
         return out
 
@@ -261,6 +271,16 @@ class Scene:
         if getattr(self, "_h", None):
             _destroy(self._h)
             self._h = None
+
+
+def decode_jpeg(data: bytes) -> np.ndarray:
+    """uint8 [h][w][channels] as `stbi_load(path, &w, &h, &channels, 0)` (scene/texture/bitmap.hpp:15) returns a baseline JPEG."""
+    buf = np.frombuffer(data, np.uint8)
+    w, h, ch = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    _check(_L.rtk_decode_jpeg(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), C.byref(ch), None, 0))
+    out = np.zeros((h.value, w.value, ch.value), np.uint8)
+    _check(_L.rtk_decode_jpeg(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), C.byref(ch), out.ctypes.data, out.size))
+    return out
 
 
 def parse_scene_file(path: str) -> Scene:

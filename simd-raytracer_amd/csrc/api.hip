@@ -117,6 +117,7 @@ struct rtk_accel {
     rtk::DevLight *d_lights = nullptr;
     rtk::DevTexture *d_textures = nullptr;
     rtk::DevTriUv *d_tri_uv = nullptr;
+    uint8_t *d_tex_pixels = nullptr;
     unsigned long long *d_counters = nullptr;     // 8 x u64 in rtk_counters order + kRayCounterShards ray-count shards
     // streaming-pipeline workspace (grown on demand)
     // one per sample lane (stream.hpp kStreamLanes); `ws` = lane 0; all lanes share lane 0's sumbuf
@@ -184,6 +185,7 @@ int ensure_device(rtk_accel *a) {
     if (!a->scene.textures.empty()) {
         if ((rc = upload(a->scene.textures, &a->d_textures)) != RTK_OK) return rc;
         if ((rc = upload(a->tree.dev_tri_uv, &a->d_tri_uv)) != RTK_OK) return rc;
+        if (!a->scene.tex_pixels.empty() && (rc = upload(a->scene.tex_pixels, &a->d_tex_pixels)) != RTK_OK) return rc;
     }
     RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->d_counters), kCounterWords * sizeof(unsigned long long)));
     RTK_HIP(hipMemset(a->d_counters, 0, kCounterWords * sizeof(unsigned long long)));
@@ -372,6 +374,7 @@ int rtk_scene_get_info(const rtk_scene *s, rtk_scene_info *info) {
     info->n_textures = int32_t(s->textures.size());
     info->n_uv_vertices = 0;
     for (const HostMesh &m : s->meshes) info->n_uv_vertices += int32_t(m.uvs.size() / 2);
+    info->n_bitmap_bytes = int32_t(s->tex_pixels.size());
     return RTK_OK;
 }
 
@@ -421,11 +424,39 @@ int rtk_scene_get_textures(const rtk_scene *s, int32_t *mat_texture, int32_t *me
     }
     for (size_t i = 0; i < s->textures.size(); ++i) {
         if (tex_kind) tex_kind[i] = s->textures[i].kind;
-        if (tex_color_a) std::memcpy(tex_color_a + i * 3, s->textures[i].a, 3 * sizeof(float));
+        const bool bmp = s->textures[i].kind == RTK_TEX_BITMAP;
+        const float zero[3] = {0.f, 0.f, 0.f};
+        if (tex_color_a) std::memcpy(tex_color_a + i * 3, bmp ? zero : s->textures[i].a, 3 * sizeof(float));
         if (tex_color_b) std::memcpy(tex_color_b + i * 3, s->textures[i].b, 3 * sizeof(float));
         if (tex_param) tex_param[i] = s->textures[i].param;
     }
     return RTK_OK;
+}
+
+int rtk_scene_get_bitmaps(const rtk_scene *s, int32_t *tex_bitmap, uint8_t *tex_pixels) {
+    if (!s) return fail(RTK_ERR_INVALID, "null scene");
+    for (size_t i = 0; i < s->textures.size(); ++i) {
+        if (!tex_bitmap) break;
+        const DevTexture &t = s->textures[i];
+        const bool bmp = t.kind == RTK_TEX_BITMAP;
+        tex_bitmap[i * 3] = bmp ? t.bmp[2] : 0; tex_bitmap[i * 3 + 1] = bmp ? t.bmp[0] : 0; tex_bitmap[i * 3 + 2] = bmp ? t.bmp[1] : 0;
+    }
+    if (tex_pixels && !s->tex_pixels.empty()) std::memcpy(tex_pixels, s->tex_pixels.data(), s->tex_pixels.size());
+    return RTK_OK;
+}
+
+int rtk_decode_jpeg(const uint8_t *data, size_t size, int32_t *width, int32_t *height, int32_t *channels, uint8_t *pixels, size_t cap) {
+    if (!data || !width || !height || !channels) return fail(RTK_ERR_INVALID, "null argument");
+    try {
+        std::vector<uint8_t> px;
+        std::string err;
+        int w = 0, h = 0, ch = 0;
+        const int rc = decode_jpeg(data, size, w, h, ch, px, err);
+        if (rc != RTK_OK) return fail(rc, err);
+        *width = w; *height = h; *channels = ch;
+        if (pixels) std::memcpy(pixels, px.data(), px.size() < cap ? px.size() : cap);
+        return RTK_OK;
+    } catch (const std::exception &e) { return fail(RTK_ERR_INVALID, e.what()); }
 }
 
 int rtk_scene_vertex_normals(const rtk_scene *s, int32_t mesh, float *out) {
@@ -511,7 +542,7 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipSetDevice(a->device);
         (void)hipFree(a->d_nodes); (void)hipFree(a->d_leaves); (void)hipFree(a->d_tris); (void)hipFree(a->d_tri_ids); (void)hipFree(a->d_shade);
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
-        (void)hipFree(a->d_textures); (void)hipFree(a->d_tri_uv);
+        (void)hipFree(a->d_textures); (void)hipFree(a->d_tri_uv); (void)hipFree(a->d_tex_pixels);
         free_stream_ws(a);
         for (auto &st : a->lane_stream) if (st) (void)hipStreamDestroy(st);
         for (auto &e : a->lane_done) if (e) (void)hipEventDestroy(e);
@@ -657,7 +688,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     std::memset(&A, 0, sizeof(A));
     A.tree = tree_view(a);
     A.materials = a->d_materials; A.lights = a->d_lights;
-    A.textures = a->d_textures; A.tri_uv = a->d_tri_uv;
+    A.textures = a->d_textures; A.tri_uv = a->d_tri_uv; A.tex_pixels = a->d_tex_pixels;
     A.n_lights = int(a->scene.lights.size());
     A.has_refractive = a->has_refractive ? 1 : 0;
     std::memcpy(A.cam_pos, a->scene.cam_pos, sizeof(A.cam_pos));

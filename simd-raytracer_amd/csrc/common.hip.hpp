@@ -64,15 +64,30 @@ static __device__ __noinline__ void det_sincos(float angle, float &s, float &c) 
     c = (float)cv;
 }
 
-// sample(texture, hit, uvs) for the procedural textures (scene/texture/albedo.hpp:9-11, edge.hpp:12-21, checker.hpp:13-28).
+// sample(texture, hit, uvs) (scene/texture/albedo.hpp:9-11, edge.hpp:12-21, checker.hpp:13-28, bitmap.hpp:46-59).
 // hit_w is evaluated in double there (`1. - hit_u - hit_v` with a double literal) and rounded to float.
-__device__ __forceinline__ V3 sample_texture(const DevTexture *T, const DevTriUv *uv, const float u, const float v) {
+__device__ __forceinline__ V3 sample_texture(const DevTexture *T, const DevTriUv *uv, const float u, const float v,
+                                             const uint8_t *tex_pixels) {
     const V3 a = mk(T->a[0], T->a[1], T->a[2]), b = mk(T->b[0], T->b[1], T->b[2]);
     if (T->kind == RTK_TEX_ALBEDO) return a;
     const float w = (float)((1.0 - (double)u) - (double)v);
     if (T->kind == RTK_TEX_EDGES) return (u < T->param || v < T->param || w < T->param) ? a : b;
     const float fx = (w * uv->uv[0] + u * uv->uv[2]) + v * uv->uv[4];          // hit_w * uvs.x + hit_u * uvs.y + hit_v * uvs.z
     const float fy = (w * uv->uv[1] + u * uv->uv[3]) + v * uv->uv[5];
+    if (T->kind == RTK_TEX_BITMAP) {
+        // bitmap.hpp:53-59: `size_t row = (1. - final_uv.y) * height` is a double product, `size_t column = final_uv.x * width` a
+        // float one (the size_t converts to F); both truncate.  A negative value is undefined there: x86-64 yields 0 above -1 and
+        // a huge number (clamped to the last row / column) below, which is what is done here.
+        const int bw = T->bmp[0], bh = T->bmp[1];
+        const double rd = (1.0 - (double)fy) * (double)bh;
+        const float cf = fx * (float)bw;
+        const long long ri = (long long)rd, ci = (long long)cf;      // NaN converts to 0 on the device; on x86 to INT64_MIN (last row)
+        const int row = (ri < 0 || ri > bh - 1 || rd != rd) ? bh - 1 : (int)ri;
+        const int col = (ci < 0 || ci > bw - 1 || cf != cf) ? bw - 1 : (int)ci;
+        const uint8_t *px = tex_pixels + (size_t)T->bmp[2] + ((size_t)row * (size_t)bw + (size_t)col) * 3u;
+        const float color_scale = (float)(1.0 / 255.0);              // bitmap.hpp:19
+        return mk((float)px[0] * color_scale, (float)px[1] * color_scale, (float)px[2] * color_scale);
+    }
     const int u2 = (int)(fx / T->param), v2 = (int)(fy / T->param);
     return ((u2 + v2) % 2 == 0) ? a : b;
 }

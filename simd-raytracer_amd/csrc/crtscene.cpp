@@ -151,6 +151,33 @@ void floats(const JValue &arr, size_t n, float *out, const char *what) { // load
     for (size_t i = 0; i < n; ++i) out[i] = f32(*arr.arr[i], what);
 }
 
+bool file_exists(const std::string &p) {
+    if (std::FILE *f = std::fopen(p.c_str(), "rb")) { std::fclose(f); return true; }
+    return false;
+}
+
+// bitmap.hpp:15 hands `file_path` to stbi_load as it stands, i.e. relative to the working directory, which the reference's README
+// asks to be its project root (README.md:32-35).  Here: as given if that exists; else below the nearest ancestor directory of
+// the scene file that holds it, also with leading components dropped (scenes/hw12/textures/x.jpg next to a copy of scenes/).
+std::string resolve_texture_path(const std::string &scene_path, const std::string &file_path) {
+    if (file_exists(file_path) || file_path.empty() || file_path[0] == '/') return file_path;
+    std::string dir = scene_path;
+    for (;;) {
+        const size_t slash = dir.find_last_of('/');
+        dir = slash == std::string::npos ? std::string() : dir.substr(0, slash);
+        const std::string base = dir.empty() ? (slash == std::string::npos ? std::string(".") : std::string("/")) : dir;
+        size_t from = 0;
+        for (;;) {
+            const std::string cand = base + "/" + file_path.substr(from);
+            if (file_exists(cand)) return cand;
+            const size_t next = file_path.find('/', from);
+            if (next == std::string::npos) break;
+            from = next + 1;
+        }
+        if (slash == std::string::npos || dir.empty()) return file_path;
+    }
+}
+
 int64_t uint_of(const JValue &v, const char *what) {
     if (v.kind != JValue::Number || v.num < 0 || v.num != static_cast<double>(static_cast<int64_t>(v.num)))
         throw Fail{RTK_ERR_PARSE, std::string(what) + ": expected an unsigned integer"};
@@ -201,13 +228,14 @@ int scene_from_crtscene(const char *path, rtk_scene &out, std::string &err) {
         // load_texture, loader.hpp:78-106; scene.textures is keyed by name there (loader.hpp:249-253), by index here
         out.textures.clear();
         std::vector<std::string> texture_names;
-        std::vector<bool> texture_is_bitmap;
+        std::vector<Fail> texture_fail;          // a bitmap file that could not be decoded: an error once a material uses it
+        out.tex_pixels.clear();
         if (const JValue *texs = root.get("textures")) {
             if (texs->kind == JValue::Array) for (const JPtr &t : texs->arr) {
                 DevTexture dt;
                 std::memset(&dt, 0, sizeof(dt));
                 const std::string &type = need(t.get(), "type", JValue::String, "texture").str;
-                bool bitmap = false;
+                Fail load_fail{RTK_OK, {}};
                 if (type == "albedo") {
                     dt.kind = RTK_TEX_ALBEDO;
                     floats(need(t.get(), "albedo", JValue::Array, "texture"), 3, dt.a, "texture.albedo");
@@ -222,12 +250,24 @@ int scene_from_crtscene(const char *path, rtk_scene &out, std::string &err) {
                     floats(need(t.get(), "color_B", JValue::Array, "texture"), 3, dt.b, "texture.color_B");
                     dt.param = f32(need(t.get(), "square_size", JValue::Number, "texture"), "texture.square_size");
                 } else if (type == "bitmap") {
-                    bitmap = true;                       // needs an image decoder: only an error if a material uses it
+                    dt.kind = RTK_TEX_BITMAP;                                 // loader.hpp:97-101, texture/bitmap.hpp:11-44
+                    const std::string &file_path = need(t.get(), "file_path", JValue::String, "texture").str;
+                    int w = 0, h = 0, ch = 0;
+                    std::vector<uint8_t> px;
+                    std::string jerr;
+                    const int jrc = load_bitmap_file(resolve_texture_path(path, file_path), w, h, ch, px, jerr);
+                    if (jrc != RTK_OK || ch != 3) dt.kind = RTK_TEX_ALBEDO;     // placeholder; using it is the error (below)
+                    if (jrc != RTK_OK) load_fail = Fail{jrc, jerr};
+                    else if (ch != 3) load_fail = Fail{RTK_ERR_UNSUPPORTED, "bitmap texture '" + file_path + "' is not a 3-channel image (bitmap.hpp:26-28 reads three)"};
+                    else {
+                        dt.bmp[0] = w; dt.bmp[1] = h; dt.bmp[2] = static_cast<int32_t>(out.tex_pixels.size());
+                        out.tex_pixels.insert(out.tex_pixels.end(), px.begin(), px.end());
+                    }
                 } else {
                     throw Fail{RTK_ERR_INVALID, "texture type unknown"};
                 }
                 texture_names.push_back(need(t.get(), "name", JValue::String, "texture").str);
-                texture_is_bitmap.push_back(bitmap);
+                texture_fail.push_back(load_fail);
                 out.textures.push_back(dt);
             }
         }
@@ -249,8 +289,7 @@ int scene_from_crtscene(const char *path, rtk_scene &out, std::string &err) {
                     for (size_t ti = 0; ti < texture_names.size(); ++ti)
                         if (texture_names[ti] == alb->str) { dm.texture = static_cast<int32_t>(ti); break; }
                     if (dm.texture < 0) throw Fail{RTK_ERR_INVALID, "material refers to unknown texture '" + alb->str + "'"};
-                    if (texture_is_bitmap[static_cast<size_t>(dm.texture)])
-                        throw Fail{RTK_ERR_UNSUPPORTED, "bitmap textures need an image decoder and are outside the accelerated path"};
+                    if (texture_fail[static_cast<size_t>(dm.texture)].code != RTK_OK) throw texture_fail[static_cast<size_t>(dm.texture)];
                 } else if (alb->kind == JValue::Array) {
                     dm.kind = RTK_MAT_DIFFUSE;
                     floats(*alb, 3, dm.albedo, "material.albedo");

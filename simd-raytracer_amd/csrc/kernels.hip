@@ -650,7 +650,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 hn = s.hit_normal; fn = s.face_normal; din = ray.d;
                 hit_tri = s.tri; hit_mat = s.material;
                 if (FORKS && A.tri_uv != nullptr && A.materials[hit_mat].kind == RTK_MAT_TEXTURE)   // texture_material: colour of this hit
-                    albedo = sample_texture(A.textures + A.materials[hit_mat].texture, A.tri_uv + hit_tri, cand.u, cand.v);
+                    albedo = sample_texture(A.textures + A.materials[hit_mat].texture, A.tri_uv + hit_tri, cand.u, cand.v, A.tex_pixels);
                 state = ST_SHADE;
             }
         }

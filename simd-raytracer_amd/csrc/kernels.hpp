@@ -38,6 +38,7 @@ struct RenderArgs {
     const DevMaterial *materials;
     const DevTexture *textures;       // procedural textures (null / unused when the scene has none)
     const DevTriUv *tri_uv;           // per-triangle uvs, only when the scene has textures
+    const uint8_t *tex_pixels;        // RGB bytes of the bitmap textures (DevTexture::bmp), null without them
     const DevLight *lights;
     int n_lights;
     int has_refractive;

@@ -56,9 +56,12 @@ struct DevMaterial {  // scene/material/*.hpp flattened
     uint32_t pad;
 };
 
-struct DevTexture {   // scene/texture/{albedo,edge,checker}.hpp flattened
+struct DevTexture {   // scene/texture/{albedo,edge,checker,bitmap}.hpp flattened
     int32_t kind;
-    float a[3];           // albedo / edge_color / color_a
+    union {
+        float a[3];       // albedo / edge_color / color_a
+        int32_t bmp[3];   // RTK_TEX_BITMAP: width, height, byte offset of the first texel in the texel buffer
+    };
     float b[3];           // - / inner_color / color_b
     float param;          // - / edge_width / square_size
 };
@@ -108,6 +111,7 @@ struct rtk_scene {
     std::vector<rtk::HostMesh> meshes;
     std::vector<rtk::DevMaterial> materials;
     std::vector<rtk::DevTexture> textures;
+    std::vector<uint8_t> tex_pixels;           // RGB bytes of all bitmap textures (bitmap.hpp:11-37), DevTexture::bmp points into it
     std::vector<rtk::DevLight> lights;
     float cam_pos[3];
     float cam_mat[9];
@@ -136,6 +140,9 @@ struct HostTree {
 int scene_from_desc(const rtk_scene_desc &d, rtk_scene &out, std::string &err);
 // crtscene.cpp
 int scene_from_crtscene(const char *path, rtk_scene &out, std::string &err);
+// jpeg.cpp: stbi_load's result for a baseline JPEG (bitmap.hpp:15)
+int decode_jpeg(const uint8_t *data, size_t size, int &width, int &height, int &channels, std::vector<uint8_t> &pixels, std::string &err);
+int load_bitmap_file(const std::string &path, int &width, int &height, int &channels, std::vector<uint8_t> &pixels, std::string &err);
 // kdtree.cpp
 int build_tree(const rtk_scene &scene, int max_depth, int max_leaf, HostTree &out, std::string &err);
 // ppm.cpp

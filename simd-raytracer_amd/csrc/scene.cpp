@@ -107,11 +107,21 @@ int scene_from_desc(const rtk_scene_desc &d, rtk_scene &out, std::string &err) {
     }
     if (d.n_textures < 0) { err = "negative texture count"; return RTK_ERR_INVALID; }
     out.textures.resize(static_cast<size_t>(d.n_textures));
+    out.tex_pixels.clear();
     for (int32_t i = 0; i < d.n_textures; ++i) {
         DevTexture &t = out.textures[static_cast<size_t>(i)];
         std::memset(&t, 0, sizeof(t));
         t.kind = d.tex_kind[i];
-        if (t.kind < RTK_TEX_ALBEDO || t.kind > RTK_TEX_CHECKER) { err = "texture type unknown"; return RTK_ERR_INVALID; }
+        if (t.kind < RTK_TEX_ALBEDO || t.kind > RTK_TEX_BITMAP) { err = "texture type unknown"; return RTK_ERR_INVALID; }
+        if (t.kind == RTK_TEX_BITMAP) {                                  // bitmap_texture, texture/bitmap.hpp:40-44
+            if (!d.tex_bitmap || !d.tex_pixels) { err = "bitmap texture without tex_bitmap / tex_pixels"; return RTK_ERR_INVALID; }
+            const int32_t *b = d.tex_bitmap + i * 3;
+            if (b[0] < 0 || b[1] <= 0 || b[2] <= 0 || static_cast<int64_t>(b[1]) * b[2] > (int64_t{1} << 28)) { err = "bad bitmap texture size"; return RTK_ERR_INVALID; }
+            const size_t n = static_cast<size_t>(b[1]) * static_cast<size_t>(b[2]) * 3;
+            t.bmp[0] = b[1]; t.bmp[1] = b[2]; t.bmp[2] = static_cast<int32_t>(out.tex_pixels.size());
+            out.tex_pixels.insert(out.tex_pixels.end(), d.tex_pixels + b[0], d.tex_pixels + b[0] + n);
+            continue;
+        }
         if (d.tex_color_a) std::memcpy(t.a, d.tex_color_a + i * 3, sizeof(float) * 3);
         if (d.tex_color_b) std::memcpy(t.b, d.tex_color_b + i * 3, sizeof(float) * 3);
         t.param = d.tex_param ? d.tex_param[i] : 0.0f;

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
                     }
                 } else if (mkind == RTK_MAT_TEXTURE) {                                          // :211-238
                     ncos = m->smooth ? hn : s.face_normal;
-                    value = sample_texture(A.textures + m->texture, A.tri_uv + s.tri, c.u, c.v);
+                    value = sample_texture(A.textures + m->texture, A.tri_uv + s.tri, c.u, c.v, A.tex_pixels);
                     kind = NODE_TEX; push_hit = true;
                 } else {                                                                        // diffuse, :148-209
                     ncos = m->smooth ? hn : s.face_normal;

@@ -44,11 +44,14 @@ struct hip_accel {
         std::vector<int32_t> mesh_material, mesh_nverts, mesh_ntris, mat_kind, mat_smooth, mat_texture, mesh_has_uvs, tex_kind;
         std::vector<float> vertices, mat_albedo, mat_ior, light_pos, light_intensity, uvs, tex_a, tex_b, tex_param;
         std::vector<uint32_t> indices;
+        std::vector<uint8_t> tex_pixels;                  // bitmap_texture::texture back as the bytes stbi_load gave (bitmap.hpp:26-28)
+        std::vector<int32_t> tex_bitmap;                  // [n_textures][3] byte offset, width, height
         // scene.textures is keyed by name (scene/scene.hpp:18); the C-ABI refers to textures by index
         std::vector<std::string> texture_names;
         for (const auto &[name, tv] : sc.textures) {
             float a[3] = {0.f, 0.f, 0.f}, b[3] = {0.f, 0.f, 0.f}, prm = 0.f;
             int kind = -1;
+            int32_t bmp[3] = {0, 0, 0};
             std::visit([&](const auto &t) {
                 using T = std::decay_t<decltype(t)>;
                 if constexpr (std::is_same_v<T, albedo_texture<F>>) { kind = RTK_TEX_ALBEDO; a[0] = t.albedo.red; a[1] = t.albedo.green; a[2] = t.albedo.blue; }
@@ -60,9 +63,18 @@ struct hip_accel {
                     kind = RTK_TEX_CHECKER; prm = t.square_size;
                     a[0] = t.color_a.red; a[1] = t.color_a.green; a[2] = t.color_a.blue;
                     b[0] = t.color_b.red; b[1] = t.color_b.green; b[2] = t.color_b.blue;
+                } else {                                  // bitmap_texture (scene/texture/bitmap.hpp:40-44)
+                    kind = RTK_TEX_BITMAP;
+                    const std::size_t h = t.texture.get_height(), w = t.texture.get_width();
+                    bmp[0] = static_cast<int32_t>(tex_pixels.size()); bmp[1] = static_cast<int32_t>(w); bmp[2] = static_cast<int32_t>(h);
+                    for (std::size_t r = 0; r < h; ++r) for (std::size_t c = 0; c < w; ++c) {
+                        const auto &px = t.texture.get_pixel(r, c);     // F(byte) * F(1.0 / 255.0), bitmap.hpp:19-28: invert exactly
+                        const F ch[3] = {px.red, px.green, px.blue};
+                        for (F v : ch) tex_pixels.push_back(static_cast<uint8_t>(v * F(255) + F(0.5)));
+                    }
                 }
             }, tv);
-            if (kind < 0) continue;                       // bitmap textures: rejected below if a material uses one
+            tex_bitmap.insert(tex_bitmap.end(), bmp, bmp + 3);
             texture_names.push_back(name);
             tex_kind.push_back(kind); tex_param.push_back(prm);
             tex_a.insert(tex_a.end(), a, a + 3); tex_b.insert(tex_b.end(), b, b + 3);
@@ -94,7 +106,7 @@ struct hip_accel {
                 else {                                    // texture_material (scene/material/texture.hpp)
                     kind = RTK_MAT_TEXTURE;
                     for (std::size_t ti = 0; ti < texture_names.size(); ++ti) if (texture_names[ti] == m.texture) texture = static_cast<int>(ti);
-                    if (texture < 0) throw std::invalid_argument("hip_accel: material uses a bitmap or unknown texture '" + m.texture + "'");
+                    if (texture < 0) throw std::invalid_argument("hip_accel: material uses unknown texture '" + m.texture + "'");
                 }
                 if constexpr (requires { m.albedo; }) { albedo[0] = m.albedo.red; albedo[1] = m.albedo.green; albedo[2] = m.albedo.blue; }
             }, mv);
@@ -114,6 +126,7 @@ struct hip_accel {
         d.mat_texture = mat_texture.data(); d.uvs = uvs.data(); d.mesh_has_uvs = mesh_has_uvs.data();
         d.n_textures = static_cast<int32_t>(tex_kind.size());
         d.tex_kind = tex_kind.data(); d.tex_color_a = tex_a.data(); d.tex_color_b = tex_b.data(); d.tex_param = tex_param.data();
+        d.tex_pixels = tex_pixels.data(); d.tex_bitmap = tex_bitmap.data();
         d.n_lights = static_cast<int32_t>(light_intensity.size());
         d.light_pos = light_pos.data(); d.light_intensity = light_intensity.data();
         d.cam_pos[0] = sc.viewpoint.position.x; d.cam_pos[1] = sc.viewpoint.position.y; d.cam_pos[2] = sc.viewpoint.position.z;

@@ -22,6 +22,10 @@ int main() {
     sc.viewpoint = {{0.f, 0.f, 0.f}, {{1, 0, 0, 0, 1, 0, 0, 0, 1}}};
     sc.lights.push_back({{0.f, 2.f, 0.f}, 100.f});
     sc.materials.push_back(diffuse_material<F>{{1.f, 1.f, 0.f}, false});
+    // a bitmap texture as load_bitmap leaves it (scene/texture/bitmap.hpp:19-28): F(byte) * F(1.0 / 255.0); the adapter hands the bytes on
+    const F cs = F(1.0 / 255.0);
+    sc.textures.emplace("bm", bitmap_texture<F>{image<F>{2, 2, {{{F(255) * cs, F(0) * cs, F(1) * cs}, {F(2) * cs, F(127) * cs, F(128) * cs}},
+                                                                 {{F(254) * cs, F(3) * cs, F(85) * cs}, {F(170) * cs, F(200) * cs, F(33) * cs}}}}});
     mesh_object<F> m{};
     m.material_idx = 0;
     m.vertices = {{-1.75f, -1.75f, -3.f}, {1.75f, -1.75f, -3.f}, {0.f, 1.75f, -3.f}};

@@ -18,7 +18,14 @@ template <typename F> using material_variant = std::variant<diffuse_material<F>,
 template <typename F> struct albedo_texture { color<F> albedo; };
 template <typename F> struct edge_texture { color<F> edge_color, inner_color; F edge_width; };
 template <typename F> struct checker_texture { color<F> color_a, color_b; F square_size; };
-template <typename F> struct bitmap_texture { std::string file_path; };
+template <typename F> struct image {                       // scene/image.hpp:7-33
+    std::size_t height, width;
+    std::vector<std::vector<color<F>>> pixels;
+    std::size_t get_height() const { return height; }
+    std::size_t get_width() const { return width; }
+    const color<F> &get_pixel(std::size_t row, std::size_t column) const { return pixels[row][column]; }
+};
+template <typename F> struct bitmap_texture { image<F> texture; };     // scene/texture/bitmap.hpp:40-44
 template <typename F> using texture_variant = std::variant<albedo_texture<F>, edge_texture<F>, checker_texture<F>, bitmap_texture<F>>;
 template <typename F> struct triangle {
     vec3<F> v0, v1, v2, e1, e2, normal;

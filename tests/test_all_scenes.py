@@ -1,4 +1,4 @@
-"""Every scene file of the reference that its own loader accepts (lights + materials present, no textures): host
+"""Every scene file of the reference that its own loader accepts (lights + materials present): host
 logic on CPU (reader + tree == oracle) and frames on the GPU (bit-exact vs the oracle through three engines).
 The scene files are the reference's input data, copied under tests/golden/scenes."""
 import glob
@@ -14,8 +14,8 @@ ALL = sorted(glob.glob(os.path.join(SCENES, "*", "*.crtscene")))
 # iterating a missing key raises simdjson_error)
 NO_LIGHTS = tuple(f"hw07/scene{i}.crtscene" for i in range(5)) + ("hw09/scene0.crtscene",)
 NO_MATERIALS = tuple(f"hw08/scene{i}.crtscene" for i in range(4)) + ("hw15/scene0.crtscene",)
-BITMAP = ("hw12/scene3.crtscene", "hw12/scene4.crtscene")                  # use the JPEG texture: needs an image decoder
-LOADABLE = [p for p in ALL if not p.endswith(NO_LIGHTS + NO_MATERIALS + BITMAP)]
+BITMAP = ("hw12/scene3.crtscene", "hw12/scene4.crtscene")                  # use the JPEG texture (scenes/hw12/textures/dragon.jpg)
+LOADABLE = [p for p in ALL if not p.endswith(NO_LIGHTS + NO_MATERIALS)]
 IDS = [os.path.relpath(p, SCENES)[:-len(".crtscene")] for p in LOADABLE]
 
 
@@ -25,7 +25,8 @@ def _bits(a):
 
 
 def test_scene_set_is_complete():
-    assert len(LOADABLE) == 22 and len(ALL) == 35            # all 35 scene files of the reference
+    assert len(LOADABLE) == 24 and len(ALL) == 35            # all 35 scene files of the reference
+    assert sum(p.endswith(BITMAP) for p in LOADABLE) == 2
 
 
 @pytest.mark.parametrize("path", [p for p in ALL if p.endswith(NO_LIGHTS + NO_MATERIALS)], ids=lambda p: os.path.basename(os.path.dirname(p)) + "/" + os.path.basename(p))
@@ -38,15 +39,6 @@ def test_scenes_the_reference_loader_rejects_are_rejected(rtk, path):
     assert e.value.code == rtk.RTK_ERR_PARSE
 
 
-@pytest.mark.parametrize("path", [p for p in ALL if p.endswith(BITMAP)], ids=lambda p: os.path.basename(os.path.dirname(p)) + "/" + os.path.basename(p))
-def test_bitmap_textured_scenes_are_refused_not_misrendered(rtk, path):
-    """bitmap_texture decodes a JPEG through stb_image (scene/texture/bitmap.hpp:11-37); there is no decoder here, so a
-    material that uses one is RTK_ERR_UNSUPPORTED.  A bitmap texture that no material uses is fine (hw12/scene0-2)."""
-    with pytest.raises(rtk.RtkError) as e:
-        rtk.parse_scene_file(path)
-    assert e.value.code == rtk.RTK_ERR_UNSUPPORTED
-
-
 @pytest.mark.parametrize("path", LOADABLE, ids=IDS)
 def test_host_side_matches_oracle(rtk, ora, path):
     sc = rtk.parse_scene_file(path)
@@ -54,7 +46,7 @@ def test_host_side_matches_oracle(rtk, ora, path):
     arr = sc.arrays()
     for k in ("mesh_material", "mesh_nverts", "mesh_ntris", "vertices", "indices", "mat_kind", "mat_albedo", "mat_ior",
               "mat_smooth", "light_pos", "light_intensity", "cam_pos", "cam_mat", "background", "mat_texture", "mesh_has_uvs",
-              "uvs", "tex_kind", "tex_color_a", "tex_color_b", "tex_param"):
+              "uvs", "tex_kind", "tex_color_a", "tex_color_b", "tex_param", "tex_bitmap", "tex_pixels"):
         assert np.array_equal(_bits(arr[k]), _bits(getattr(flat, k))), k
     box, link, refs = rtk.KdTreeSimdAccel(sc).tree_dump()
     obox, olink, orefs = ora.Accel(ora.Scene(flat), ora.ACCEL_KD_SIMD, W=16).dump()

@@ -117,7 +117,14 @@ def test_reader_error_reporting(rtk, tmp_path):
     expect(lambda d: d.pop("camera"), rtk.RTK_ERR_PARSE)
     expect(lambda d: d["materials"][1].update(albedo="brick"), rtk.RTK_ERR_INVALID)           # texture that does not exist
     expect(lambda d: (d.update(textures=[{"name": "brick", "type": "bitmap", "file_path": "x.jpg"}]),
-                      d["materials"][1].update(albedo="brick")), rtk.RTK_ERR_UNSUPPORTED)     # bitmap texture in use
+                      d["materials"][1].update(albedo="brick")), rtk.RTK_ERR_IO)              # bitmap texture in use, file missing
+    notjpeg = tmp_path / "tex.png"
+    notjpeg.write_bytes(b"\x89PNG\r\n\x1a\n" + bytes(64))
+    expect(lambda d: (d.update(textures=[{"name": "brick", "type": "bitmap", "file_path": str(notjpeg)}]),
+                      d["materials"][1].update(albedo="brick")), rtk.RTK_ERR_UNSUPPORTED)     # only baseline JPEG is decoded
+    unused = rtk.parse_scene_file(_write_scene(tmp_path, lambda d: d.update(
+        textures=[{"name": "brick", "type": "bitmap", "file_path": "x.jpg"}])))               # undecodable but unused: loads
+    assert unused.info.n_textures == 1 and unused.info.n_bitmap_bytes == 0
     ok = rtk.parse_scene_file(_write_scene(tmp_path, lambda d: d["settings"]["image_settings"].update(bucket_size=24)))
     assert ok.info.bucket_size == 24 and ok.info.n_triangles == 2
     assert rtk.parse_scene_file(_write_scene(tmp_path, lambda d: None)).info.bucket_size == 64  # loader.hpp:48

@@ -1,8 +1,8 @@
 """Pins the CPU oracle to facts MEASURED ON THE REFERENCE ITSELF and recorded in SURVEY.md (§0.4, §6, §8).
 
 The reference ships no tests or golden vectors and cannot be built in this image without stand-in headers,
-so these reference-measured counters are the only pin available ("parity unpinned" at the per-pixel level
-against a reference binary — see oracle/rt_oracle.h).  They are strong: the per-frame intersect-call count
+so these reference-measured counters pin the per-ray work; the per-pixel pin is tests/test_reference_outputs.py (the
+reference's own committed renders).  The counters are strong too: the per-frame intersect-call count
 depends on every shading-relevant hit/miss decision of the frame.
 """
 import numpy as np
