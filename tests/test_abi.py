@@ -24,12 +24,13 @@ def test_library_exports_every_declared_symbol(rtk):
 
 
 def test_abi_version_and_struct_sizes(rtk):
-    assert rtk.abi_version() == 3
+    assert rtk.abi_version() == 4                        # 4: bitmap textures (rtk_scene_desc.tex_pixels / tex_bitmap, rtk_scene_info.n_bitmap_bytes)
     assert rtk.RAY_DTYPE.itemsize == 24
     assert rtk.HIT_DTYPE.itemsize == 32
     assert ctypes.sizeof(rtk.Counters) == 64
     assert ctypes.sizeof(rtk.AccelParams) == 20
     assert ctypes.sizeof(rtk.RenderParams) == 72        # 64 + sample_begin, sample_count (ABI 3)
+    assert ctypes.sizeof(rtk.SceneInfo) == 44 and ctypes.sizeof(rtk.SceneDesc) == 264
 
 
 def test_trace_mode_constants_match_the_header(rtk):
