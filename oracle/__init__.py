@@ -222,7 +222,7 @@ def load_crtscene(path: str, bitmaps: bool = True) -> FlatScene:
     st = doc["settings"]
     img = st["image_settings"]
     tex_names, tkind, ta, tb, tp, tbitmap = [], [], [], [], [], []
-    tpix, tbmp = [], []
+    tpix, tbmp, tfail = [], [], []
     for t in doc.get("textures", []) if isinstance(doc.get("textures", []), list) else []:      # loader.hpp:78-106
         ty = t["type"]
         tex_names.append(t["name"])
@@ -237,11 +237,18 @@ def load_crtscene(path: str, bitmaps: bool = True) -> FlatScene:
             tkind.append(TEX_BITMAP); ta.append([0, 0, 0]); tb.append([0, 0, 0]); tp.append(0.0)
         else:
             raise ValueError("texture type unknown")  # loader.hpp:104
+        tfail.append(None)
         if ty == "bitmap" and bitmaps:
             from . import stb_jpeg
-            px = stb_jpeg.load(resolve_texture_path(path, t["file_path"]))
-            if px.shape[2] != 3:
-                raise NotImplementedError("bitmap.hpp:26-28 reads three channels per pixel")
+            try:                                  # a file that cannot be decoded is an error once a material uses the texture
+                px = stb_jpeg.load(resolve_texture_path(path, t["file_path"]))
+                if px.shape[2] != 3:
+                    raise NotImplementedError("bitmap.hpp:26-28 reads three channels per pixel")
+            except (OSError, ValueError, NotImplementedError) as e:
+                tfail[-1] = e
+                tkind[-1] = TEX_ALBEDO
+                tbmp.append([0, 0, 0])
+                continue
             tbmp.append([sum(len(x) for x in tpix), px.shape[1], px.shape[0]])
             tpix.append(px.reshape(-1))
         else:
@@ -257,6 +264,8 @@ def load_crtscene(path: str, bitmaps: bool = True) -> FlatScene:
             tex = tex_names.index(m["albedo"])
             if tbitmap[tex] and not bitmaps:
                 raise NotImplementedError("bitmap texture (decode with bitmaps=True)")
+            if tfail[tex] is not None:
+                raise tfail[tex]
             kinds.append(MAT_TEXTURE)
             alb.append([0, 0, 0])
         else:
