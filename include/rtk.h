@@ -65,8 +65,11 @@ enum {
                              (repack.hip: Morton key over the dimensions that vary, rocPRIM radix sort), then traced in that
                              order -- wave-cooperatively when the sort makes tight waves, with the per-lane fallback otherwise;
                              hits land in the caller's order, bit-identical to every other mode.  Needs 16 B of workspace
-                             per ray (kept by the accel).  RTK_TRACE_AUTO does this by itself for large incoherent batches;
-                             RTK_REPACK=0 in the environment turns that off */
+                             per ray (kept by the accel; a later batch on another stream waits, on the device, for the batch
+                             that is still walking it).  Never blocks the host.  RTK_TRACE_AUTO does this by itself for large
+                             incoherent batches -- after a probe whose verdict costs one stream synchronisation, so AUTO on
+                             2^18 rays and more is not stream-capturable; RTK_REPACK=0 in the environment turns the probe and
+                             the sort off */
 };
 
 typedef struct rtk_scene rtk_scene;   /* replaces scene<F>, scene/scene.hpp:14-22 */
@@ -229,6 +232,7 @@ int rtk_accel_intersect_stats(rtk_accel *accel, const rtk_ray *d_rays, size_t n,
 /* ---- frame: replaces render_frame<A,F> (render/render.hpp:18-108) with color_hit/is_occluded device-side ---- */
 /* number of floats the (rank-local) output of rtk_render_frame_device holds */
 int rtk_render_output_floats(const rtk_accel *accel, const rtk_render_params *p, size_t *n_floats);
+/* host variant: a pass with sample_begin > 0 uploads `rgb` (the running sums of the passes before it) first */
 int rtk_render_frame(rtk_accel *accel, const rtk_render_params *p, float *rgb /* host [h][w][3] */,
                      rtk_counters *counters /* may be NULL */);
 /* world_size <= 1: d_out is the frame [h][w][3].  world_size > 1: d_out is this rank's compact bucket

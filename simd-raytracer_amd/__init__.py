@@ -368,14 +368,19 @@ class KdTreeSimdAccel:
         _check(_L.rtk_render_output_floats(self._h, C.byref(p), C.byref(n)))
         return n.value
 
-    def render_frame(self, cfg: RenderConfig):
-        """Whole frame into host memory: ([h,w,3] float32, counters dict)."""
+    def render_frame(self, cfg: RenderConfig, rgb: np.ndarray | None = None):
+        """Whole frame into host memory: ([h,w,3] float32, counters dict).  `rgb`: the buffer to render into -- for a later
+        pass of a progressive frame (cfg.sample_begin > 0) it holds the running sums of the passes before."""
         w = cfg.width or self.scene.info.width
         h = cfg.height or self.scene.info.height
         p = cfg.to_c()
         n = self.output_floats(cfg)
         assert n == w * h * 3
-        rgb = np.zeros((h, w, 3), np.float32)
+        if rgb is None:
+            if cfg.sample_begin > 0:
+                raise ValueError("a pass with sample_begin > 0 needs the buffer the previous passes rendered into")
+            rgb = np.zeros((h, w, 3), np.float32)
+        assert rgb.dtype == np.float32 and rgb.shape == (h, w, 3) and rgb.flags.c_contiguous
         c = Counters()
         _check(_L.rtk_render_frame(self._h, C.byref(p), rgb.ctypes.data, C.byref(c)))
         return rgb, c.as_dict()

@@ -149,6 +149,8 @@ struct rtk_accel {
     // ray repacking workspace (batched intersect, repack.hip)
     uint32_t *rp_bounds = nullptr, *rp_keys = nullptr, *rp_idx = nullptr;
     void *rp_temp = nullptr;
+    hipEvent_t rp_done = nullptr;    // recorded behind the k_intersect that walks rp_idx: the next repack on any stream waits for it
+    bool rp_in_use = false;
     size_t rp_temp_bytes = 0, rp_cap = 0;
     unsigned fb_age = 0;             // frames rendered with the current order
     hipStream_t last_stream = nullptr;
@@ -557,6 +559,7 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipFree(a->rp_bounds); (void)hipFree(a->rp_keys); (void)hipFree(a->rp_idx); (void)hipFree(a->rp_temp);
         (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
         for (auto &e : a->trial_ev) if (e) (void)hipEventDestroy(e);
+        if (a->rp_done) (void)hipEventDestroy(a->rp_done);
     }
     delete a;
 }
@@ -596,28 +599,44 @@ static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, 
     const bool big = n >= (size_t(1) << 18) && n < (size_t(1) << 32);
     const bool forced = mode == RTK_TRACE_REPACK;
     if (forced) mode = RTK_TRACE_AUTO;
-    if (!stats && ((forced && n >= 2 && n < (size_t(1) << 32)) || (mode == RTK_TRACE_AUTO && a->knobs.repack && big))) {
+    const bool sortable = !stats && n >= 2 && n < (size_t(1) << 32);
+    const bool probe = !stats && !forced && mode == RTK_TRACE_AUTO && a->knobs.repack && big;
+    if ((forced && sortable) || probe) {
         int rc = ensure_repack_ws(a, n);
         if (rc != RTK_OK) return rc;
-        hipError_t eb = launch_ray_bounds(d_rays, n, a->rp_bounds, forced && !big ? 2u : 16u, s);
-        if (eb != hipSuccess) return hip_fail(eb, "launch k_ray_bounds (probe)");
-        uint32_t h[kRepackBoundsWords];
-        RTK_HIP(hipMemcpyAsync(h, a->rp_bounds, sizeof(h), hipMemcpyDeviceToHost, s));
-        RTK_HIP(hipStreamSynchronize(s));
-        const RepackProbe pr = decode_probe(h);
-        const bool incoherent = pr.wide_dir_fraction >= 0.25f || pr.origin_spread >= 0.25f;
-        if (forced || incoherent) {
+        // The workspace (bounds, keys, permutation) belongs to the accel: a batch on another stream may still be walking the
+        // permutation of the previous call.  Its k_intersect recorded rp_done; this stream waits for it before it rewrites anything.
+        if (a->rp_done == nullptr) RTK_HIP(hipEventCreateWithFlags(&a->rp_done, hipEventDisableTiming));
+        if (a->rp_in_use) RTK_HIP(hipStreamWaitEvent(s, a->rp_done, 0));
+        hipError_t eb = hipSuccess;
+        bool sort = forced;
+        int sorted_mode = RTK_TRACE_AUTO;                                    // any order: wave-cooperative with the per-lane fallback
+        if (probe) {
+            // AUTO: the probe's verdict is needed on the host (one stream synchronisation; RTK_TRACE_REPACK and RTK_REPACK=0 never block)
+            eb = launch_ray_bounds(d_rays, n, a->rp_bounds, 16u, s);
+            if (eb != hipSuccess) return hip_fail(eb, "launch k_ray_bounds (probe)");
+            uint32_t h[kRepackBoundsWords];
+            RTK_HIP(hipMemcpyAsync(h, a->rp_bounds, sizeof(h), hipMemcpyDeviceToHost, s));
+            RTK_HIP(hipStreamSynchronize(s));
+            const RepackProbe pr = decode_probe(h);
+            sort = pr.wide_dir_fraction >= 0.25f || pr.origin_spread >= 0.25f;
+            if (pr.active_dims <= 3) sorted_mode = RTK_TRACE_WAVE;           // ten bits per dimension: the sort makes tight waves
+            if (!sort) mode = RTK_TRACE_WAVE;                                // coherent as it comes
+        }
+        if (sort) {
             eb = launch_ray_bounds(d_rays, n, a->rp_bounds, 1u, s);
             if (eb == hipSuccess) eb = launch_ray_sort(d_rays, n, a->rp_bounds, a->rp_keys, a->rp_idx, a->rp_temp, a->rp_temp_bytes, s);
             if (eb != hipSuccess) return hip_fail(eb, "ray repacking");
             A.perm = a->rp_idx + n;
-            mode = a->knobs.repack_trace >= 0 ? a->knobs.repack_trace : (pr.active_dims <= 3 ? RTK_TRACE_WAVE : RTK_TRACE_AUTO);
-        } else {
-            mode = RTK_TRACE_WAVE;                                           // coherent as it comes
+            mode = a->knobs.repack_trace >= 0 ? a->knobs.repack_trace : sorted_mode;
         }
     }
     const hipError_t e = launch_intersect(A, mode, stats, s);
     if (e != hipSuccess) return hip_fail(e, "launch k_intersect");
+    if (A.perm != nullptr) {
+        RTK_HIP(hipEventRecord(a->rp_done, s));
+        a->rp_in_use = true;
+    }
     return RTK_OK;
 }
 
@@ -957,8 +976,11 @@ int rtk_render_frame(rtk_accel *a, const rtk_render_params *p, float *rgb, rtk_c
         if (rc != RTK_OK) return rc;
         float *d_out = nullptr;
         RTK_HIP(hipMalloc(reinterpret_cast<void **>(&d_out), nf * sizeof(float)));
-        rc = render_device_impl(a, p, d_out, nullptr);
         hipError_t e = hipSuccess;
+        // a later pass of a progressive frame continues the running per-pixel sums the previous pass left in `rgb`
+        if (p->sample_begin > 0) e = hipMemcpy(d_out, rgb, nf * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d_out); return hip_fail(e, "upload of the running sums"); }
+        rc = render_device_impl(a, p, d_out, nullptr);
         if (rc == RTK_OK) e = hipMemcpy(rgb, d_out, nf * sizeof(float), hipMemcpyDeviceToHost);
         (void)hipFree(d_out);
         if (rc != RTK_OK) return rc;

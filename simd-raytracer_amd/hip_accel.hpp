@@ -178,6 +178,10 @@ struct hip_accel {
 
     // render_frame<A,F>(accel, BUCKET_TILES) with the whole loop device-side; pixels [h][w] as in image<F>
     [[nodiscard]] std::vector<std::vector<color<F>>> render_frame(const rtk_render_params &params, rtk_counters *counters = nullptr) const {
+        // this returns a finished image: a partial pass of a progressive frame (sample_begin / sample_count) needs the running
+        // sums of the passes before it, which live in the caller's buffer -- use rtk_render_frame / _device for those
+        if (params.sample_begin != 0 || (params.sample_count != 0 && params.sample_count != params.spp))
+            throw std::invalid_argument("hip_accel::render_frame renders whole frames (sample_begin = 0, all spp samples)");
         std::size_t n = 0;
         check(rtk_render_output_floats(accel_.get(), &params, &n));
         std::vector<float> rgb(n);

@@ -53,9 +53,9 @@ int main(int argc, char **argv) {
     }
     // --world N: the rank processes are forked here, before this process has made any GPU call
     int rank = 0;
-    std::string id_path;
+    rtk_multi_link link;
     if (world >= 1) {
-        rank = rtk_multi_fork(world, id_path);
+        rank = rtk_multi_fork(world, link);
         if (rank < 0) return -1 - rank;                 // the launcher: every rank has exited
         ap.device = -1;
     }
@@ -65,9 +65,7 @@ int main(int argc, char **argv) {
     rtk_scene_get_info(scene, &info);
     const int w = p.width > 0 ? p.width : info.width, h = p.height > 0 ? p.height : info.height;
     if (world >= 1) {
-        int n_dev = 0;
-        rtk_device_count(&n_dev);                       // (counting devices does not initialise one)
-        ap.device = n_dev > 0 ? rank % n_dev : -1;
+        ap.device = rank;                               // rank r renders on device r (rtk_multi_rank refuses world > devices)
     }
     rtk_accel *accel = nullptr;
     if (rtk_accel_build(scene, &ap, &accel) != RTK_OK) return die("accel");
@@ -76,7 +74,7 @@ int main(int argc, char **argv) {
         std::vector<float> rgb;
         double best = 0.0;
         unsigned long long rays = 0;
-        if (rtk_multi_rank(accel, p, rank, world, id_path.c_str(), frames, rgb, best, rays) != 0) return 1;
+        if (rtk_multi_rank(accel, p, rank, world, link, frames, rgb, best, rays) != 0) return 1;
         if (rank == 0) {
             std::printf("Rendering took %g seconds.\n", best);
             std::printf("%llu rays on %d GPUs, %.1f Mrays/s (render + RCCL all-gather + assemble, frame left on the device)\n", rays, world, double(rays) / best / 1e6);

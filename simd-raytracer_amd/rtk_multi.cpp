@@ -4,10 +4,12 @@
 // twin of simd-raytracer_amd/parallel.py; the engine library itself (librtk_hip.so) stays free of RCCL.
 //
 // Process model: `rtk_render --world N` forks N rank processes BEFORE anything touches the GPU (the launcher process never
-// initialises HIP), rank r takes device r.  Rank 0 creates the ncclUniqueId and publishes it through a
-// file (write to a temporary name, then rename: readers never see a partial id).
+// initialises HIP), rank r takes device r.  Rank 0 creates the ncclUniqueId and hands it to every other rank through a pipe
+// the launcher opened before the fork: no path in the file system is shared.  The launcher waits for ANY child; the first one
+// that fails takes the others down with it (SIGTERM), so a rank that dies never leaves its peers blocked in a collective.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <signal.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -29,67 +31,100 @@ namespace {
 #define MG_NCCL(call) do { const ncclResult_t r_ = (call); if (r_ != ncclSuccess) { std::fprintf(stderr, "rtk_render[%d]: %s: %s\n", rank, #call, ncclGetErrorString(r_)); return 1; } } while (0)
 #define MG_RTK(call) do { if ((call) != RTK_OK) { std::fprintf(stderr, "rtk_render[%d]: %s: %s\n", rank, #call, rtk_last_error()); return 1; } } while (0)
 
-bool read_id(const std::string &path, ncclUniqueId &id) {
-    std::FILE *f = std::fopen(path.c_str(), "rb");
-    if (!f) return false;
-    const size_t n = std::fread(&id, 1, sizeof(id), f);
-    std::fclose(f);
-    return n == sizeof(id);
+bool read_all(int fd, void *buf, size_t n) {
+    char *p = static_cast<char *>(buf);
+    while (n > 0) {
+        const ssize_t got = read(fd, p, n);
+        if (got <= 0) return false;                    // 0: rank 0 went away without sending the id
+        p += got; n -= static_cast<size_t>(got);
+    }
+    return true;
+}
+bool write_all(int fd, const void *buf, size_t n) {
+    const char *p = static_cast<const char *>(buf);
+    while (n > 0) {
+        const ssize_t put = write(fd, p, n);
+        if (put <= 0) return false;
+        p += put; n -= static_cast<size_t>(put);
+    }
+    return true;
 }
 
 }  // namespace
 
 // The launcher: forks `world` children BEFORE anything touches the GPU (the parent never initialises HIP and only waits).
 // Returns the rank (0..world-1) in a child, and -1 - status in the parent once every child has exited.
-int rtk_multi_fork(int world, std::string &id_path) {
-    char tmpl[] = "/tmp/rtk_nccl_id_XXXXXX";
-    const int fd = mkstemp(tmpl);
-    if (fd < 0) { std::perror("rtk_render: mkstemp"); return -2; }
-    close(fd);
-    unlink(tmpl);                                      // rank 0 creates it (atomically, by rename) once the id exists
-    id_path = tmpl;
+int rtk_multi_fork(int world, rtk_multi_link &link) {
+    if (world < 1 || world > 64) { std::fprintf(stderr, "rtk_render: --world must be 1..64\n"); return -2; }
+    std::vector<int> rd(static_cast<size_t>(world), -1), wr(static_cast<size_t>(world), -1);
+    for (int r = 1; r < world; ++r) {                  // one pipe per rank > 0: rank 0 writes the id, rank r reads it
+        int fds[2];
+        if (pipe(fds) != 0) { std::perror("rtk_render: pipe"); return -2; }
+        rd[static_cast<size_t>(r)] = fds[0]; wr[static_cast<size_t>(r)] = fds[1];
+    }
     setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);      // dmabuf IPC between the ranks' processes
     std::vector<pid_t> kids;
     for (int r = 0; r < world; ++r) {
         const pid_t pid = fork();
-        if (pid < 0) { std::perror("rtk_render: fork"); return -2; }
-        if (pid == 0) return r;
+        if (pid < 0) {
+            std::perror("rtk_render: fork");
+            for (const pid_t k : kids) kill(k, SIGTERM);
+            return -2;
+        }
+        if (pid == 0) {
+            signal(SIGPIPE, SIG_IGN);                  // a peer that died shows up as a failed write, not as a signal
+            link.id_read_fd = -1; link.id_write_fds.clear();
+            for (int q = 1; q < world; ++q) {
+                if (r == 0) { close(rd[static_cast<size_t>(q)]); link.id_write_fds.push_back(wr[static_cast<size_t>(q)]); }
+                else {
+                    close(wr[static_cast<size_t>(q)]);
+                    if (q == r) link.id_read_fd = rd[static_cast<size_t>(q)]; else close(rd[static_cast<size_t>(q)]);
+                }
+            }
+            return r;
+        }
         kids.push_back(pid);
     }
+    for (int r = 1; r < world; ++r) { close(rd[static_cast<size_t>(r)]); close(wr[static_cast<size_t>(r)]); }
     int rc = 0;
-    for (const pid_t pid : kids) {
+    size_t left = kids.size();
+    while (left > 0) {                                  // whichever child ends first is seen first
         int st = 0;
-        if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+        const pid_t pid = waitpid(-1, &st, 0);
+        if (pid < 0) { rc = 1; break; }
+        bool mine = false;
+        for (pid_t &k : kids) if (k == pid) { k = -1; mine = true; }
+        if (!mine) continue;
+        left -= 1;
+        if ((!WIFEXITED(st) || WEXITSTATUS(st) != 0) && rc == 0) {
+            rc = 1;
+            for (const pid_t k : kids) if (k > 0) kill(k, SIGTERM);   // its peers would wait for it in the next collective forever
+        }
     }
-    unlink(id_path.c_str());
     return -1 - rc;
 }
 
 // One rank: renders `frames` frames of its buckets, gathers, assembles; rank 0 returns the last frame in `rgb_out`.
-int rtk_multi_rank(rtk_accel *accel, rtk_render_params p, int rank, int world, const char *id_path, int frames,
+int rtk_multi_rank(rtk_accel *accel, rtk_render_params p, int rank, int world, const rtk_multi_link &link, int frames,
                    std::vector<float> &rgb_out, double &best_seconds, unsigned long long &rays_total) {
     int n_dev = 0;
     MG_HIP(hipGetDeviceCount(&n_dev));
     if (n_dev < 1) { std::fprintf(stderr, "rtk_render[%d]: no HIP device\n", rank); return 1; }
-    MG_HIP(hipSetDevice(rank % n_dev));
+    if (world > n_dev) {                               // RCCL refuses (or hangs on) two ranks of one communicator on one device
+        if (rank == 0) std::fprintf(stderr, "rtk_render: --world %d but only %d HIP device(s)\n", world, n_dev);
+        return 1;
+    }
+    MG_HIP(hipSetDevice(rank));
     ncclUniqueId id;
     if (rank == 0) {
         MG_NCCL(ncclGetUniqueId(&id));
-        const std::string tmp = std::string(id_path) + ".tmp";
-        std::FILE *f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(&id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0 || std::rename(tmp.c_str(), id_path) != 0) {
-            std::fprintf(stderr, "rtk_render[0]: cannot publish the RCCL id at %s\n", id_path);
-            return 1;
+        for (const int fd : link.id_write_fds) {
+            if (!write_all(fd, &id, sizeof(id))) { std::fprintf(stderr, "rtk_render[0]: cannot send the RCCL id to a rank\n"); return 1; }
+            close(fd);
         }
     } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (!read_id(id_path, id)) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
-                std::fprintf(stderr, "rtk_render[%d]: timed out waiting for the RCCL id\n", rank);
-                return 1;
-            }
-            std::this_thread::sleep_for(std::chrono::milliseconds(5));
-        }
+        if (!read_all(link.id_read_fd, &id, sizeof(id))) { std::fprintf(stderr, "rtk_render[%d]: rank 0 ended before it sent the RCCL id\n", rank); return 1; }
+        close(link.id_read_fd);
     }
     ncclComm_t comm;
     MG_NCCL(ncclCommInitRank(&comm, world, id, rank));
@@ -134,6 +169,12 @@ int rtk_multi_rank(rtk_accel *accel, rtk_render_params p, int rank, int world, c
     MG_HIP(hipMemcpyAsync(d_rays, &mine, sizeof(mine), hipMemcpyHostToDevice, stream));
     MG_NCCL(ncclAllReduce(d_rays, d_rays, 1, ncclUint64, ncclSum, comm, stream));
     MG_HIP(hipMemcpyAsync(&rays_total, d_rays, sizeof(rays_total), hipMemcpyDeviceToHost, stream));
+    MG_HIP(hipStreamSynchronize(stream));
+    // the frame takes as long as its slowest rank: max over the ranks of each rank's best time
+    static_assert(sizeof(double) == sizeof(unsigned long long), "the 8-byte scratch word carries the time as well");
+    MG_HIP(hipMemcpyAsync(d_rays, &best_seconds, sizeof(double), hipMemcpyHostToDevice, stream));
+    MG_NCCL(ncclAllReduce(d_rays, d_rays, 1, ncclDouble, ncclMax, comm, stream));
+    MG_HIP(hipMemcpyAsync(&best_seconds, d_rays, sizeof(double), hipMemcpyDeviceToHost, stream));
     MG_HIP(hipStreamSynchronize(stream));
     if (rank == 0) {
         rgb_out.resize(n_frame);

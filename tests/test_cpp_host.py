@@ -69,3 +69,18 @@ def test_rtk_render_cli_world_path_through_rccl(rtk, ora, tmp_path):
     ref, cn = ora.Accel(ora.Scene(ora.load_crtscene(SCENE5)), ora.ACCEL_KD_SIMD).render(320, 180, 1, 5, 0, fov_degrees=75.0)
     assert out.read_bytes() == ora.write_ppm(ref)
     assert f"{cn['rays']} rays on 1 GPUs" in res.stdout
+
+
+@pytest.mark.gpu
+def test_rtk_render_cli_refuses_more_ranks_than_devices_and_does_not_hang(rtk, tmp_path):
+    """`--world N` with N > devices: every rank sees it and leaves; the launcher reports failure instead of waiting for ranks that
+    would block in RCCL.  The RCCL id travels through pipes, so nothing is left under /tmp either."""
+    import torch
+
+    n = torch.cuda.device_count()
+    exe = os.path.join(PKG, "rtk_render")
+    before = set(os.listdir("/tmp"))
+    res = subprocess.run([exe, SCENE5, "--width", "64", "--height", "36", "--world", str(n + 1), "--out", str(tmp_path / "x.ppm")],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and f"--world {n + 1} but only {n} HIP device" in res.stderr
+    assert not [f for f in set(os.listdir("/tmp")) - before if f.startswith("rtk_nccl_id")]
