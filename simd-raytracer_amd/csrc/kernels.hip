@@ -159,6 +159,24 @@ struct ShadowBurstService {
     }
 };
 
+// The lane index, computed where it is asked for.  From threadIdx / __lane_id() the compiler derives a dozen per-lane
+// constants in the kernel's prologue (pixel coordinates as floats, the pixel's RNG hash, its output address, one LDS
+// address per array and stride, 1 << lane as a 64-bit pair ...), keeps them across the traversal loops and, out of registers
+// there, spills every one of them to scratch right away: 22 dwords per lane written by each of a frame's 32,400 owner waves,
+// 180 MB of HBM traffic per launch.  An `asm volatile` is opaque and is not hoisted: two instructions at each use instead.
+__device__ __forceinline__ uint32_t fresh_lane() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+// a ray whose inv_direction is filled in by k_render right before the query (see there)
+__device__ __forceinline__ Ray spawn_ray(const V3 o, const V3 d) {
+    Ray r;
+    r.o = o; r.d = d; r.inv = d;
+    return r;
+}
+
 enum : int { ST_NEW_SAMPLE = 0, ST_TRACE, ST_SHADE, ST_LIGHT, ST_RETURN, ST_DONE };
 enum : int { PEND_CHILD_BG = 0, PEND_CHILD_BLACK = 1, PEND_SHADOW = 2 };
 enum : uint32_t { FR_REFR_A = 0, FR_REFR_B = 1, FR_DIFFUSE = 2 };
@@ -239,7 +257,6 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     __shared__ __attribute__((aligned(16))) float wave_bundles[4][kMaxBundles * kBundleFloats];
     SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, light ? 0xFFFFFFFFu : A.slice_min_tris, 0u, true, 0u,
                    (SLICES > 1 && !light) ? group_sh->bundles : wave_bundles[wave_in_wg & 3u]};
-    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t park_slot = (SLICES > 1 && !light) ? 0u : (wave_in_wg & 3u);
     const unsigned long long cost_t0 = __builtin_readcyclecounter();
     const unsigned long long real_t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, for the frame's critical path (bench.py)
@@ -249,10 +266,20 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     const uint32_t bucket = (uint32_t)A.rank + local_bucket * (uint32_t)A.world;
     bool valid = bucket < A.n_buckets;
     const uint32_t bx = (bucket % A.tiles_x) * A.bucket, by = (bucket / A.tiles_x) * A.bucket;
-    const uint32_t lx = (sub % A.blocks_per_bucket_side) * 8u + (lane & 7u);
-    const uint32_t ly = (sub / A.blocks_per_bucket_side) * 8u + (lane >> 3);
-    const uint32_t px = bx + lx, py = by + ly;
-    valid = valid & (lx < A.bucket) & (ly < A.bucket) & (px < A.width) & (py < A.height);
+    const uint32_t sub_x0 = (sub % A.blocks_per_bucket_side) * 8u, sub_y0 = (sub / A.blocks_per_bucket_side) * 8u;   // wave-uniform
+    // this lane's pixel: recomputed where it is needed (see fresh_lane) instead of living in registers across the traversal
+    struct Pixel { uint32_t lx, ly, px, py; };
+    const auto my_pixel = [&]() {
+        const uint32_t l = fresh_lane();
+        Pixel p;
+        p.lx = sub_x0 + (l & 7u); p.ly = sub_y0 + (l >> 3);
+        p.px = bx + p.lx; p.py = by + p.ly;
+        return p;
+    };
+    {
+        const Pixel p = my_pixel();
+        valid = valid & (p.lx < A.bucket) & (p.ly < A.bucket) & (p.px < A.width) & (p.py < A.height);
+    }
 
 #ifdef RTK_DEBUG_PHASES
     const unsigned long long ph_begin = __builtin_readcyclecounter();
@@ -260,19 +287,20 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     const V3 background = mk(A.background[0], A.background[1], A.background[2]);
     const V3 black = mk(0.f, 0.f, 0.f);
     const float PI_F = 3.14159265358979323846f;
-    const uint32_t pixel = py * A.width + px;
     const uint32_t seed_hash = pcg_hash(A.seed);
 
     // ---- per-lane path state
     int state = valid ? ST_NEW_SAMPLE : ST_DONE;
     int pend = PEND_CHILD_BG;
     int sample = A.sample_begin, depth = 0, light_k = 0;
-    uint32_t rkey = 0, nrays = 0;         // rkey: RNG key of the ray in flight (position in the sample's ray tree)
+    uint32_t rkey = 0;                    // RNG key of the ray in flight (position in the sample's ray tree)
+    uint32_t nrays_wave = 0;              // rays of the whole wave so far (wave-uniform: a scalar, not a register per lane)
     bool cull = false;
-    Ray ray = make_ray(black, mk(1.f, 1.f, 1.f));
+    Ray ray = spawn_ray(black, mk(1.f, 1.f, 1.f));
     V3 pixel_sum = black, ret = black;
     if (A.sample_begin > 0 && valid) {                                     // a later pass of a progressive frame: the running sum so far
-        const float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
+        const Pixel p = my_pixel();
+        const float *o = A.out + A.out_index(local_bucket, p.lx, p.ly, p.px, p.py) * 3;
         pixel_sum = mk(o[0], o[1], o[2]);
     }
     // hit being shaded / lit
@@ -306,7 +334,8 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 if (sample == A.sample_end) {
                     const float inv = A.spp_f;
                     if (writer) {
-                        float *o = A.out + A.out_index(local_bucket, lx, ly, px, py) * 3;
+                        const Pixel p = my_pixel();
+                        float *o = A.out + A.out_index(local_bucket, p.lx, p.ly, p.px, p.py) * 3;
                         // the last pass divides (render.hpp:72; x / 1.0f == x, bit for bit); earlier passes leave the running sum
                         if (A.spp == 1 || A.sample_end != A.spp) { o[0] = pixel_sum.x; o[1] = pixel_sum.y; o[2] = pixel_sum.z; }
                         else { o[0] = pixel_sum.x / inv; o[1] = pixel_sum.y / inv; o[2] = pixel_sum.z / inv; }
@@ -314,8 +343,9 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                     state = ST_DONE;
                     continue;
                 }
-                rkey = root_key(seed_hash, pixel, (uint32_t)sample);
-                ray = camera_ray(A, px, py, rkey);
+                const Pixel p = my_pixel();
+                rkey = root_key(seed_hash, p.py * A.width + p.px, (uint32_t)sample);
+                ray = camera_ray(A, p.px, p.py, rkey);
                 mirror_apex = ray.o;
                 cull = true; depth = 0; pend = PEND_CHILD_BG; fsp = 0;
                 primed = PRIMED;
@@ -332,7 +362,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                     const V3 ro = P + (A.reflection_bias * rd);
                     // the reflected line leaves the mirror image of the incoming line's apex: as far behind P as that apex was
                     mirror_apex = P - ((length(P - mirror_apex) / length(rd)) * rd);
-                    ray = make_ray(ro, rd);
+                    ray = spawn_ray(ro, rd);
                     rkey = child_key(rkey, 0u);
                     cull = false; depth += 1; pend = PEND_CHILD_BG;
                     state = ST_TRACE;
@@ -346,7 +376,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                     const V3 rd = i - ((2.0f * dot(i, n)) * n);
                     const V3 ro = P + (A.reflection_bias * rd);
                     if (eta_r / eta_i < sin_i_n) {                                              // total internal reflection
-                        ray = make_ray(ro, rd);
+                        ray = spawn_ray(ro, rd);
                         rkey = child_key(rkey, 0u);
                         cull = false; depth += 1; pend = PEND_CHILD_BLACK;
                         state = ST_TRACE;
@@ -364,7 +394,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                             f.meta = FR_REFR_A | ((uint32_t)depth << 8);
                             f.key = rkey;
                         }
-                        ray = make_ray(P + (A.refraction_bias * r), r);
+                        ray = spawn_ray(P + (A.refraction_bias * r), r);
                         rkey = child_key(rkey, 0u);
                         cull = false; depth += 1; pend = PEND_CHILD_BLACK;
                         state = ST_TRACE;
@@ -407,7 +437,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 const float cosine = (0.0f < d0) ? d0 : 0.0f;                // std::max(0, dot)
                 contrib = (L->intensity / area) * cosine;
                 if (0.0f < radius) {                                         // is_occluded's loop guard, :114
-                    ray = make_ray(P + (A.shadow_bias * ld), ld);
+                    ray = spawn_ray(P + (A.shadow_bias * ld), ld);
                     shadow_max_t = radius;
                     cull = false; pend = PEND_SHADOW;
                     state = ST_TRACE;
@@ -428,7 +458,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 if (kind == FR_REFR_A) {                                     // refraction subtree done -> reflection ray
                     f.a[7] = ret.x; f.a[8] = ret.y; f.a[9] = ret.z;
                     f.meta = FR_REFR_B | ((uint32_t)fdepth << 8);
-                    ray = make_ray(mk(f.a[0], f.a[1], f.a[2]), mk(f.a[3], f.a[4], f.a[5]));
+                    ray = spawn_ray(mk(f.a[0], f.a[1], f.a[2]), mk(f.a[3], f.a[4], f.a[5]));
                     rkey = child_key(f.key, 1u);
                     cull = false; depth = fdepth + 1; pend = PEND_CHILD_BLACK;
                     state = ST_TRACE;
@@ -462,7 +492,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                         const V3 dir = mk(right.x * rv.x + right.y * rv.y + right.z * rv.z,
                                           up.x * rv.x + up.y * rv.y + up.z * rv.z,
                                           fwd.x * rv.x + fwd.y * rv.y + fwd.z * rv.z);
-                        ray = make_ray(org, dir);
+                        ray = spawn_ray(org, dir);
                         rkey = child_key(f.key, (uint32_t)it);
                         cull = false; depth = fdepth + 1; pend = PEND_CHILD_BLACK;
                         state = ST_TRACE;
@@ -493,9 +523,14 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         // resolve pass, never across a trace.  Saying so keeps twelve registers out of the traversal loops (the difference
         // between 5 resident waves per SIMD with scratch spills and 5 without).
         hn = black; fn = black; din = black; ret = black;
+        hit_tri = 0u; hit_mat = 0u;              // likewise: set when a hit is consumed, read by the ST_SHADE that follows at once
         // Most queries of a frame never enter the tree (background): the root box is tested first, and when no lane passes
         // nothing else is set up -- no parking, no bundles.
         constexpr bool kRootFirst = !STATS && MODE == RTK_TRACE_WAVE;
+        // ray3's inv_direction (ray3.hpp:11-14): the same three divisions, made here instead of where the ray is spawned -- the
+        // quotients are only read by the box tests of the query, and would otherwise sit in (or be spilled from) three
+        // registers from the shading code to this point
+        ray.inv = mk((1.0f / ray.d.x), (1.0f / ray.d.y), (1.0f / ray.d.z));
         const bool in_root = kRootFirst ? enters_root(A.tree, ray, need) : need;
         // light burst (ShadowBurstService): every lane about to query a light is at the same light, and more lights follow
         bool burst = false;
@@ -524,7 +559,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         // State that is live across the query but not used by it waits in LDS instead of in registers: with it the
         // traversal loops overflow the 96 registers of a 5-waves-per-SIMD build into scratch (measured: a background block
         // spent more time on scratch reloads than on its rays).  [var][lane] layout: conflict-free, 36 LDS operations per query.
-        float *const park = &park_lds[park_slot][0][lane];
+        float *const park = &park_lds[park_slot][0][fresh_lane()];
         park[0 * 64] = pixel_sum.x; park[1 * 64] = pixel_sum.y; park[2 * 64] = pixel_sum.z;
         park[3 * 64] = acc.x; park[4 * 64] = acc.y; park[5 * 64] = acc.z;
         park[6 * 64] = albedo.x; park[7 * 64] = albedo.y; park[8 * 64] = albedo.z;
@@ -534,10 +569,11 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         if (PRIMED && wave_any(primed)) {
             // first iteration of the pass: every pending ray is a camera ray whose hit the first pass already found
             if (need) {
-                const float4 pc = A.prim[A.out_index(local_bucket, lx, ly, px, py)];
+                const Pixel p = my_pixel();
+                const float4 pc = A.prim[A.out_index(local_bucket, p.lx, p.ly, p.px, p.py)];
                 cand.t = pc.x; cand.u = pc.y; cand.v = pc.z; cand.k = __float_as_uint(pc.w);
-                nrays -= 1;                                                 // counted by the first pass
             }
+            nrays_wave -= (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(need));   // counted by the first pass
             primed = false;
             burst_done = false;
         } else {
@@ -559,12 +595,17 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 apex = mk(L->pos[0], L->pos[1], L->pos[2]);
             }
             if (burst) {
+                const uint32_t lane = fresh_lane();
                 group_sh->ray_o[lane] = make_float4(P.x, P.y, P.z, ncos.x);
                 group_sh->ray_d[lane] = make_float4(ncos.y, ncos.z, 0.f, 0.f);
                 if (lane == 0u) {
                     group_sh->pass_mask = burst_mask; group_sh->first = burst_k; group_sh->count = burst_plog | ((burst_nl << burst_plog) << 8);
                     group_sh->pad[0] = 1u;                                  // next job to hand out (job 0 is traced right here)
-                    group_sh->kind = GROUP_EXTRA;
+                    // (an opaque constant: folded, it becomes one lane of a three-register tuple {first, count, kind} that is
+                    // set up in the kernel's prologue and spilled to scratch until it is needed here)
+                    uint32_t extra = GROUP_EXTRA;
+                    asm volatile("" : "+v"(extra));
+                    group_sh->kind = extra;
                 }
                 __syncthreads();                                            // B1: the helpers start on their lights
                 sx.min_tris = 0xFFFFFFFFu;                                  // (they are busy: the owner's own leaves stay whole)
@@ -593,17 +634,20 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
 #endif
         }
 
-        pixel_sum = mk(park[0 * 64], park[1 * 64], park[2 * 64]);
-        acc = mk(park[3 * 64], park[4 * 64], park[5 * 64]);
-        albedo = mk(park[6 * 64], park[7 * 64], park[8 * 64]);
-        ncos = mk(park[9 * 64], park[10 * 64], park[11 * 64]);
-        P = mk(park[12 * 64], park[13 * 64], park[14 * 64]);
-        mirror_apex = mk(park[15 * 64], park[16 * 64], park[17 * 64]);
+        float *const unpark = &park_lds[park_slot][0][fresh_lane()];
+        pixel_sum = mk(unpark[0 * 64], unpark[1 * 64], unpark[2 * 64]);
+        acc = mk(unpark[3 * 64], unpark[4 * 64], unpark[5 * 64]);
+        albedo = mk(unpark[6 * 64], unpark[7 * 64], unpark[8 * 64]);
+        ncos = mk(unpark[9 * 64], unpark[10 * 64], unpark[11 * 64]);
+        P = mk(unpark[12 * 64], unpark[13 * 64], unpark[14 * 64]);
+        mirror_apex = mk(unpark[15 * 64], unpark[16 * 64], unpark[17 * 64]);
         }
 
         // ---------- consume
+        uint32_t more_rays = 0u;                 // this lane's rays of this iteration (<= 1 + the lights of a burst)
         if (need) {
-            nrays += 1;
+            const uint32_t lane = fresh_lane();
+            more_rays = 1u;
             const bool hit = cand.k != kMiss;
             if (pend == PEND_SHADOW) {                                       // is_occluded, render.hpp:110-131
                 bool clear = !hit | (shadow_max_t < cand.t);
@@ -634,7 +678,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                                 const uint32_t fl = __float_as_uint(res.z);
                                 if ((fl & 2u) != 0u) {
                                     if (res.y != 0.0f) acc = acc + (res.x * albedo);
-                                    nrays += fl & 1u;
+                                    more_rays += fl & 1u;
                                 }
                             }
                             light_k += 1;
@@ -654,9 +698,18 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
                 state = ST_SHADE;
             }
         }
+        // (added up here, in uniform control flow, bit by bit through ballots: four scalar popcounts)
+        nrays_wave += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((more_rays & 1u) != 0u)) +
+                      2u * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((more_rays & 2u) != 0u)) +
+                      4u * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((more_rays & 4u) != 0u)) +
+                      8u * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((more_rays & 8u) != 0u));
+        static_assert(kBurstMaxJobs + 1u <= 15u, "a lane's rays of one iteration fit four bits");
     }
 
+    const uint32_t lane = fresh_lane();
 #ifdef RTK_DEBUG_PHASES
+    const Pixel dbg_p = my_pixel();
+    const uint32_t lx = dbg_p.lx, ly = dbg_p.ly, px = dbg_p.px, py = dbg_p.py;
     if (valid && writer) {
         const unsigned long long ph_now = __builtin_readcyclecounter();
         const unsigned long long ph_rt1 = __builtin_amdgcn_s_memrealtime();
@@ -688,7 +741,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
         if (lane == 0u && dt >= kCriticalMinTicks) atomicMax(A.counters + kCriticalWord + (gwave % (uint32_t)kRayCounterShards), dt);
     }
     if (SLICES > 1 && !light) group_post_exit(group_sh);
-    const uint32_t total = wave_sum(nrays);
+    const uint32_t total = nrays_wave;
     if (STATS && writer) flush_stats(st, 0u, A.counters);
     // one no-return atomic per pixel block, spread over 64 words (a single word saturates near 88 atomics/us)
     if (lane == 0u && writer) atomicAdd(A.counters + 8 + (gwave % (uint32_t)kRayCounterShards), (unsigned long long)total);
@@ -852,6 +905,10 @@ hipError_t launch_intersect(const dev::IntersectArgs &A, int mode, bool stats, h
 }
 
 hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool forks, hipStream_t s) {
+#ifdef RTK_ONLY_LEAN_G4     // `make asm-lean`: the benchmark's kernel alone, for quick looks at its ISA (not a product build)
+    hipLaunchKernelGGL((dev::k_render<RTK_TRACE_WAVE, false, false, false, 4>), dim3(A.n_units), dim3(256), 0, s, A);
+    return hipGetLastError();
+#else
     const size_t lds_bytes = (size_t)A.tree.n_nodes * sizeof(DevNode);
     const bool lds = lds_bytes <= kMaxNodeLdsBytes;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
@@ -867,6 +924,7 @@ hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool fo
         case RTK_TRACE_GROUP16: return launch_render_mode<RTK_TRACE_WAVE, 16>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
         default: return launch_render_mode<RTK_TRACE_AUTO, 1>(A, packed, stats, forks, lds, lds_bytes, s);
     }
+#endif
 }
 
 // Counting sort of the pixel blocks by last frame's cost, most expensive first.  One workgroup: a frame has tens of
@@ -1003,6 +1061,9 @@ hipError_t launch_twopass(const dev::RenderArgs &A, bool stats, bool forks, hipS
     const uint64_t tiles = (uint64_t)A.buckets_per_rank * bpb;
     if (tiles == 0) return hipSuccess;
     if (tiles > A.tile_cap) return hipErrorInvalidValue;
+#ifdef RTK_ONLY_LEAN_G4
+    return hipErrorNotSupported;
+#else
     hipError_t e = hipMemsetAsync(A.bin_count, 0, (kCostBins + 1) * sizeof(uint32_t), s);      // + n_listed
     if (e != hipSuccess) return e;
     if (stats) hipLaunchKernelGGL((dev::k_primary<true, 4>), dim3((unsigned)tiles), dim3(256), 0, s, A);
@@ -1016,6 +1077,7 @@ hipError_t launch_twopass(const dev::RenderArgs &A, bool stats, bool forks, hipS
         else hipLaunchKernelGGL((dev::k_render<RTK_TRACE_WAVE, false, false, false, 4, true>), dim3((unsigned)tiles), dim3(256), 0, s, A);
     }
     return hipGetLastError();
+#endif
 }
 
 hipError_t launch_camera_rays(const dev::RenderArgs &A, int sample, rtk_ray *d_rays, hipStream_t s) {
