@@ -6,9 +6,10 @@ One "step" = one full frame through the hot path (primary + shadow + reflection 
 one rank per GPU: buckets are dealt round-robin to ranks, each rank renders its buckets, the bucket buffers
 are all-gathered over RCCL/xGMI and assembled into the frame on every rank (part of the timed step).
 
-Prints ONE JSON line on rank 0 with the driver's contract plus `roofline`, `cpu_baseline` and -- outside the timed
-headline, N = 1 only -- `first_frame_ms`, `critical_path_ms` and `extras` (the fixed 2^24-ray synthetic workload of
-SURVEY 8(d) and one frame each of BASELINE configs 3 and 4's shape).
+Prints ONE JSON line on rank 0 with the driver's contract plus `roofline`, `cpu_baseline`, `verified` (the timed frame
+compared bit for bit with the CPU oracle's) and -- outside the timed headline -- `first_frame_ms`, `critical_path_ms` and
+`extras`: the fixed 2^24-ray synthetic workload of SURVEY 8(d) (at any N: sharded by contiguous ray ranges, hits all-gathered
+over RCCL) and, at N = 1, BASELINE configs 3, 4 and 5 at their real frame sizes.
 
 The headline `ms_per_step` is the STEADY STATE of a repeated frame: from the second frame of a shape on, the pixel blocks
 are started most-expensive-first using the cycle counts the previous frame reported (every block is rendered in full every
@@ -39,6 +40,27 @@ VALU_PEAK_GINSTR = N_SIMDS * CLOCK_GHZ / CYCLES_PER_WAVE_VALU
 TRACE_NAMES = {0: "auto", 1: "lane", 2: "wave", 3: "group4", 4: "group8", 5: "group16", 6: "stream", 7: "twopass", 8: "repack"}
 
 
+def code_hash() -> str:
+    """Hash of the device code the profiles describe: every kernel source and the build flags."""
+    import hashlib
+
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "simd-raytracer_amd")
+    for rel in sorted(glob.glob(os.path.join(base, "csrc", "*.hip")) + glob.glob(os.path.join(base, "csrc", "*.hpp")) + [os.path.join(base, "Makefile")]):
+        h.update(os.path.basename(rel).encode())
+        h.update(open(rel, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_meta(tag: str) -> dict:
+    """profiles/<tag>_meta.json (tools/summarize_profile.py): the code hash and git head the PMC passes were taken at."""
+    path = os.path.join(ROOT, "profiles", tag + "_meta.json")
+    try:
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return {}
+
+
 def committed_profile():
     """Per-launch PMC means of k_render from the newest committed rocprofv3 passes (profiles/r*_pmc_means.csv +
     *_traffic.json, written by tools/profile_bench.sh + tools/summarize_profile.py from separate --pmc runs of this command)."""
@@ -58,8 +80,48 @@ def committed_profile():
                     traffic = json.load(open(tpath))
                 except ValueError:
                     traffic = None
-            best = {"tag": tag, "counters": vals, "traffic": traffic, "path": os.path.relpath(path, ROOT)}
+            meta = profile_meta(tag)
+            best = {"tag": tag, "counters": vals, "traffic": traffic, "path": os.path.relpath(path, ROOT), "meta": meta,
+                    "current": bool(meta) and meta.get("code_hash") == code_hash()}
     return best
+
+
+def workload_profile(name: str):
+    """Per-frame (or per-launch) PMC sums of one `extras` workload from the newest committed profiles/r*_workloads.json
+    (tools/profile_workloads.py under rocprofv3, summarised by tools/summarize_profile.py)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_workloads.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if name in doc.get("workloads", {}):
+            w = dict(doc["workloads"][name])
+            w["source"] = os.path.relpath(path, ROOT)
+            w["current"] = doc.get("code_hash") == code_hash()
+            w["git_head"] = doc.get("git_head")
+            return w
+    return None
+
+
+def frame_roofline(name: str, ms: float):
+    """VALU-issue fraction, wait share and HBM traffic of one extras frame: committed counters / live time."""
+    w = workload_profile(name)
+    if not w or ms <= 0:
+        return None
+    c = w["per_unit"]
+    valu = c.get("SQ_INSTS_VALU")
+    hbm = (c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024) if ("FETCH_SIZE" in c and "WRITE_SIZE" in c) else None
+    ok = w["current"]
+    return {
+        "bound": "valu_issue", "unit": "G wave-instr/s", "peak": VALU_PEAK_GINSTR,
+        "achieved": (valu / (ms * 1e-3) / 1e9) if (valu and ok) else None,
+        "frac": (valu / (ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR) if (valu and ok) else None,
+        "valu_instructions": valu,
+        "wait_share": (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
+        "traffic": hbm, "hbm_frac": (hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (hbm and ok) else None,
+        "kernel_launches": w.get("launches_per_unit"),
+        "counters_source": w["source"], "profile_matches_code": ok, "profile_git_head": w.get("git_head"),
+    }
 
 
 def algorithmic_bytes(c: dict) -> int:
@@ -106,15 +168,11 @@ def event_ms(torch, stream, fn, n):
     return a.elapsed_time(b) / n
 
 
-def extras(rtk, torch, stream) -> dict:
-    """Outside the timed headline: the slow workloads, so that they are visible in the driver-run line."""
+def synthetic_rays(rtk, torch, stream, n: int):
+    """SURVEY 8(d)'s three fixed ray sets on scene5 (the same on every rank: fixed seeds)."""
     import numpy as np
 
-    out = {}
-    # ---- SURVEY 8(d): N = 2^24 rays through rtk_accel_intersect_device on scene5's tree
-    scene = rtk.parse_scene_file(SCENE)
-    acc = rtk.KdTreeSimdAccel(scene)
-    n = 1 << 24
+    acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(SCENE))
     cfg = rtk.RenderConfig(width=WIDTH, height=HEIGHT)
     cam = torch.empty((HEIGHT * WIDTH, 6), dtype=torch.float32, device="cuda")
     acc.camera_rays_device(cfg, cam.data_ptr(), 0, stream.cuda_stream)        # the 1920x1080 pixel-centre rays, row-major
@@ -126,42 +184,102 @@ def extras(rtk, torch, stream) -> dict:
     o = rng.uniform([-15, -5, -15], [15, 8.82, 15], size=(n, 3)).astype(np.float32)
     v = rng.normal(size=(n, 3)).astype(np.float32); v /= np.linalg.norm(v, axis=1, keepdims=True)
     secondary = torch.from_numpy(np.concatenate([o, v], axis=1).astype(np.float32)).cuda()
-    hits = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    return acc, (("coherent_primary", coherent, True), ("shuffled_primary", shuffled, True), ("uniform_secondary", secondary, False))
+
+
+def synthetic_extras(rtk, torch, dist, stream, rank: int, world: int) -> dict:
+    """N = 2^24 rays through rtk_accel_intersect_device on scene5's tree.  At world > 1 the batch is cut into
+    contiguous ray ranges, one per rank, and the 32-byte hits are all-gathered over RCCL inside the timed region; the time of a
+    launch is the slowest rank's.  The path has no other exchange step: rays are independent."""
+    n = 1 << 24
+    acc, sets = synthetic_rays(rtk, torch, stream, n)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    m = hi - lo
+    hits = torch.empty((n, 32), dtype=torch.uint8, device="cuda")            # the gathered result (rank order == ray order)
+    mine = hits[lo:hi] if world == 1 else torch.empty((m, 32), dtype=torch.uint8, device="cuda")
     synth = {}
-    for name, rays, cull in (("coherent_primary", coherent, True), ("shuffled_primary", shuffled, True), ("uniform_secondary", secondary, False)):
-        cn = acc.intersect_stats(rays.data_ptr(), n, cull, hits.data_ptr(), 2)
+    for name, rays, cull in sets:
+        part = rays[lo:hi]
+        cn = acc.intersect_stats(part.data_ptr(), m, cull, mine.data_ptr(), 2)
         best = None
         for mode in (2, 0, 8):      # (0 = auto repacks by itself when its probe finds the batch incoherent; the sort is inside the timed call)
+            def launch():
+                acc.intersect_device(part.data_ptr(), m, cull, mine.data_ptr(), mode, stream.cuda_stream)
+                if world > 1:
+                    dist.all_gather_into_tensor(hits.view(-1), mine.view(-1))
             for _ in range(2):
-                acc.intersect_device(rays.data_ptr(), n, cull, hits.data_ptr(), mode, stream.cuda_stream)
-            ms = min(event_ms(torch, stream, lambda: acc.intersect_device(rays.data_ptr(), n, cull, hits.data_ptr(), mode, stream.cuda_stream), 1)
-                     for _ in range(5))
+                launch()
+            ms = min(event_ms(torch, stream, launch, 1) for _ in range(5))
+            if world > 1:
+                t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = float(t[0])
             if best is None or ms < best[0]:
                 best = (ms, TRACE_NAMES[mode])
-        b_alg = 32 * cn["nodes"] + 36 * cn["tris"] + 64 * n
-        synth[name] = {"ms": best[0], "Mrays_s": n / best[0] / 1e3, "mode": best[1], "hit_fraction": cn["hits"] / n,
-                       "nodes_per_ray": cn["nodes"] / n, "tris_per_ray": cn["tris"] / n, "algorithmic_GBps": b_alg / best[0] / 1e6}
-    out["synthetic_2p24"] = {"workload": "SURVEY 8(d): 2^24 rays on scene5's tree through rtk_accel_intersect_device (56 B of ray + hit "
-                                         "per ray in HBM); coherent = the 1920x1080 camera rays tiled, shuffled = the same set permuted (seed 42), "
-                                         "uniform_secondary = origins uniform in the scene box, directions uniform on the sphere (seed 43); "
-                                         "best of 5 launches, fastest of the wave, auto and repack strategies (repack: the rays sorted by origin / direction cell "
-                                         "first, the sort inside the timed call)", **synth}
-    del coherent, shuffled, secondary, hits, cam
-    # ---- one frame each of BASELINE config 3 and of config 4's shape (RTK_TRACE_AUTO picks the engine on the first frames)
+        tot = torch.tensor([float(cn["nodes"]), float(cn["tris"]), float(cn["hits"])], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tot)
+        nodes, tris, nhit = (float(x) for x in tot)
+        b_alg = 32 * nodes + 36 * tris + 64 * n
+        hbm_gbps = 56.0 * n / best[0] / 1e6                                   # 24 B ray in + 32 B hit out, each moved once
+        synth[name] = {"ms": best[0], "Mrays_s": n / best[0] / 1e3, "mode": best[1], "hit_fraction": nhit / n,
+                       "nodes_per_ray": nodes / n, "tris_per_ray": tris / n, "algorithmic_GBps": b_alg / best[0] / 1e6,
+                       "hbm_GBps": hbm_gbps, "hbm_frac": hbm_gbps / HBM_PEAK_GBPS}
+        if world == 1:
+            r = frame_roofline("synthetic_" + name, best[0])
+            if r:
+                synth[name]["roofline"] = r
+    return {"workload": "SURVEY 8(d): 2^24 rays on scene5's tree through rtk_accel_intersect_device; coherent = the 1920x1080 camera rays tiled, "
+                        "shuffled = the same set permuted (seed 42), uniform_secondary = origins uniform in the scene box, directions uniform on "
+                        "the sphere (seed 43); best of 5 launches, fastest of the wave, auto and repack strategies (repack: the rays sorted by "
+                        "origin / direction cell first, the sort inside the timed call).  hbm_GBps = 56 B per ray (24 B ray in + 32 B hit out) / ms, "
+                        "hbm_frac against 8 TB/s: the bytes this path has to move, the tree itself is cache resident"
+                        + (f"; {world} ranks: contiguous ray ranges, the hits all-gathered over RCCL inside the timed region, slowest rank's time" if world > 1 else ""),
+            "n_gpus": world, **synth}
+
+
+def frame_extras(rtk, torch, stream) -> dict:
+    """BASELINE configs 3, 4 and 5 at their real frame sizes (N = 1; RTK_TRACE_AUTO picks the engine on the first frames)."""
     frames = {}
-    for name, path, kw in (
-            ("config3_scene8_1080p_spp4_depth10", os.path.join(SCENES, "hw11", "scene8.crtscene"), dict(width=1920, height=1080, spp=4, max_ray_depth=10)),
-            ("config4_shape_scene2_960x960_spp8_depth5_gi1", os.path.join(SCENES, "hw15", "scene2.crtscene"), dict(width=960, height=960, spp=8, max_ray_depth=5, diffuse_rays=1))):
-        a = rtk.KdTreeSimdAccel(rtk.parse_scene_file(path))
-        c = rtk.RenderConfig(**kw)
-        buf = torch.empty((a.output_floats(c),), dtype=torch.float32, device="cuda")
-        for _ in range(5):
-            a.render_frame_device(c, buf.data_ptr(), stream.cuda_stream)
-        ms = min(event_ms(torch, stream, lambda: a.render_frame_device(c, buf.data_ptr(), stream.cuda_stream), 1) for _ in range(3))
-        rays = a.last_counters()["rays"]
-        frames[name] = {"ms": ms, "rays": rays, "Mrays_s": rays / ms / 1e3}
-    out["frames"] = frames
-    return out
+
+    def timed_passes(a, kw, passes, reps):
+        c = [rtk.RenderConfig(**kw, sample_begin=b, sample_count=n) if n else rtk.RenderConfig(**kw) for b, n in passes]
+        buf = torch.empty((a.output_floats(c[0]),), dtype=torch.float32, device="cuda")
+        rays = [0]
+
+        def run():
+            rays[0] = 0
+            for cfg in c:
+                a.render_frame_device(cfg, buf.data_ptr(), stream.cuda_stream)
+                rays[0] += 0 if len(c) == 1 else a.last_counters()["rays"]
+        for _ in range(reps[0]):
+            run()
+        ms = min(event_ms(torch, stream, run, 1) for _ in range(reps[1]))
+        if len(c) == 1:
+            rays[0] = a.last_counters()["rays"]
+        return ms, rays[0]
+
+    scene8 = os.path.join(SCENES, "hw11", "scene8.crtscene")
+    scene2 = os.path.join(SCENES, "hw15", "scene2.crtscene")
+    # config 3 as quoted
+    a = rtk.KdTreeSimdAccel(rtk.parse_scene_file(scene8))
+    ms, rays = timed_passes(a, dict(width=1920, height=1080, spp=4, max_ray_depth=10), [(0, 0)], (5, 3))
+    frames["config3_scene8_1080p_spp4_depth10"] = {"ms": ms, "rays": rays, "Mrays_s": rays / ms / 1e3, "spp_timed": 4,
+                                                   "roofline": frame_roofline("config3", ms)}
+    # config 4 as quoted: 1920x1920 (the scene's own size and bucket 24), 128 spp in 8 passes of 16 (progressive accumulation)
+    a = rtk.KdTreeSimdAccel(rtk.parse_scene_file(scene2))
+    kw = dict(spp=128, max_ray_depth=5, diffuse_rays=1)
+    ms, rays = timed_passes(a, kw, [(16 * k, 16) for k in range(8)], (1, 1))
+    frames["config4_scene2_1920x1920_spp128_depth5_gi1"] = {"ms": ms, "rays": rays, "Mrays_s": rays / ms / 1e3, "spp_timed": 128,
+                                                            "passes": "8 x 16 samples", "roofline": frame_roofline("config4", ms / 8)}
+    # config 5's frame: 3840x2160, depth 10, one diffuse ray, spp = 512 in the RNG keys; 16 of the 512 samples are timed (two
+    # passes of 8); the other 31 pairs of passes do the same work on other samples
+    kw = dict(width=3840, height=2160, spp=512, max_ray_depth=10, diffuse_rays=1)
+    ms, rays = timed_passes(a, kw, [(0, 8), (8, 8)], (1, 2))
+    frames["config5_scene2_3840x2160_spp512_depth10_gi1"] = {
+        "ms": ms, "rays": rays, "Mrays_s": rays / ms / 1e3, "spp_timed": 16, "passes": "2 x 8 of the 512 samples",
+        "full_frame_ms_extrapolated": ms * 32, "roofline": frame_roofline("config5", ms / 2)}
+    return frames
 
 
 def main() -> None:
@@ -172,7 +290,8 @@ def main() -> None:
     ap.add_argument("--trace-mode", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra workloads (synthetic 2^24 rays, configs 3 and 4)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra workloads (synthetic 2^24 rays, configs 3-5)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison of the timed frame with the CPU oracle's")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="N>1: frames in flight (1 = render, gather, assemble back to back)")
     args = ap.parse_args()
 
@@ -291,6 +410,21 @@ def main() -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
+    # ---- the frame that was just timed, checked: bit for bit the CPU oracle's frame (rank 0; for N > 1 the assembled frame)
+    verified, verify_note = None, None
+    if rank == 0 and not args.no_verify:
+        import numpy as np
+        import oracle
+
+        timed_frame = (frame if pipe is None else pipe.last_frame()).detach().cpu().numpy()
+        oacc = oracle.Accel(oracle.Scene(oracle.load_crtscene(SCENE)), oracle.ACCEL_KD_SIMD)
+        ref, ocn = oacc.render(WIDTH, HEIGHT, SPP, DEPTH, DIFFUSE, count_work=False)
+        same = bool(np.array_equal(timed_frame.view(np.uint32), ref.view(np.uint32)))
+        verified = same
+        verify_note = (f"frame of the last timed step vs oracle/rt_oracle.c (kd_tree_simd_accel restatement, fp-contract off; itself pinned to the "
+                       f"reference's own renders by tests/test_reference_outputs.py): {'all' if same else 'NOT all'} {ref.size} floats bit-equal, "
+                       f"oracle ray count {ocn['rays']}")
+
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     rays_rank = accel.last_counters()["rays"]
     critical_ms = accel.last_critical_path_ms()
@@ -306,6 +440,13 @@ def main() -> None:
     else:
         rays_total = float(tot[1])
 
+    if verified is not None and world == 1:
+        verified = verified and (int(rays_total) == ocn["rays"])
+    extras_out = None
+    if not args.no_extras:
+        extras_out = {"synthetic_2p24": synthetic_extras(rtk, torch, dist, stream, rank, world)}      # every rank takes part
+        if world == 1:
+            extras_out["frames"] = frame_extras(rtk, torch, stream)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # the dominant kernel is k_render; one launch processes this rank's share of the frame
@@ -314,7 +455,9 @@ def main() -> None:
         alg_gbps = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         valu = prof["counters"]["SQ_INSTS_VALU"] if prof else None
         traffic = (prof["traffic"] or {}).get("hbm_bytes_per_launch") if prof else None
-        achieved = valu / (kernel_ms * 1e-3) / 1e9 if (valu and kernel_ms > 0) else None
+        # the counters are only as good as the code they were taken from: a profile of other kernel sources gives no fraction
+        fresh = bool(prof and prof["current"])
+        achieved = valu / (kernel_ms * 1e-3) / 1e9 if (valu and kernel_ms > 0 and fresh) else None
         out = {
             "metric": "Mrays/s (intersect invocations per second), hw09/scene5 dragon 1920x1080 1spp",
             "value": rays_total / (elapsed / args.steps) / 1e6,
@@ -343,14 +486,16 @@ def main() -> None:
                 "bound": "valu_issue",
                 "achieved": achieved, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
                 "frac": (achieved / VALU_PEAK_GINSTR) if achieved else None,
-                "traffic": traffic,
+                "traffic": traffic if fresh else None,
+                "profile_matches_code": fresh if prof else None,
+                "profile_git_head": (prof["meta"].get("git_head") if prof else None), "code_hash": code_hash(),
                 "kernel": "k_render", "kernel_ms": kernel_ms,
                 "valu_instructions_per_launch": valu,
                 "counters_source": (f"{prof['path']} (rocprofv3 --pmc passes of this command, mean per k_render launch); peak = {N_SIMDS} SIMDs x "
                                     f"{CLOCK_GHZ} GHz / {CYCLES_PER_WAVE_VALU} cycles per wave64 VALU instruction (MI355X_MICROARCH.md, Wave scheduling)") if prof else None,
                 "critical_path_frac": (critical_ms / kernel_ms) if kernel_ms > 0 else None,
-                "hbm": {"traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if (traffic and kernel_ms > 0) else None,
-                        "frac_of_8TBps": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and kernel_ms > 0) else None},
+                "hbm": {"traffic_GBps": (traffic / (kernel_ms * 1e-3) / 1e9) if (traffic and kernel_ms > 0 and fresh) else None,
+                        "frac_of_8TBps": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and kernel_ms > 0 and fresh) else None},
                 "algorithmic": {
                     "note": "SURVEY 8(d) accounting, informational: 32 B/node popped + 36 B/triangle tested + 64 B ray+hit.  These are bytes the "
                             "algorithm REFERENCES, not bytes moved: one fetch serves a whole wave and the tree is cache resident, so the rate "
@@ -364,8 +509,14 @@ def main() -> None:
                 },
             },
         }
-        if world == 1 and not args.no_extras:
-            out["extras"] = extras(rtk, torch, stream)
+        out["verified"] = verified
+        out["verified_how"] = verify_note
+        if world > 1:
+            out["config"]["scaling_note"] = ("tile sharding of THIS frame is bounded by its longest 8x8 pixel block (critical_path_ms): predicted ~1.3x "
+                                             "at any N (profiles/r02_rank_times.json: slowest rank 0.207 / 0.202 / 0.164 / 0.157 ms at N = 1 / 2 / 4 / 8); "
+                                             "frames whose blocks are small against the frame scale: config 5's shape 6.0x kernel-only at 8 ranks")
+        if extras_out is not None:
+            out["extras"] = extras_out
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -160,7 +160,10 @@ typedef struct {
     double fov_degrees;             /* fov_degrees */
     float shadow_bias, reflection_bias, refraction_bias;
     int32_t trace_mode;             /* RTK_TRACE_* */
-    int32_t rank, world_size;       /* bucket i is rendered by rank i % world_size; world_size <= 1: whole frame */
+    int32_t rank, world_size;       /* world_size <= 1: whole frame.  Else this rank's share of the scene's buckets
+                                     * (render/tile/bucket.hpp:7-21, row-major): bucket i belongs to rank i % world_size -- or,
+                                     * when a row of buckets is a whole number of rounds (tiles_x % world_size == 0, which would give
+                                     * every rank the same columns), bucket (bx, by) to rank (bx + by) % world_size */
     int32_t collect_stats;          /* 1 = also count nodes/leaves/triangles per ray, as the reference algorithm visits them
                                      * (slower kernel variant); 2 = count what the production path visits (its occlusion
                                      * queries stop at the first answering hit when no material is transmissive; same frame) */

@@ -285,6 +285,7 @@ bool valid_frame_mode(int m) { return valid_mode(m) || m == RTK_TRACE_GROUP4 || 
 
 struct FrameGeom {
     uint32_t width, height, bucket, tiles_x, tiles_y, n_buckets, blocks_side, buckets_per_rank;
+    uint32_t skew_q;                   // kernels.hpp rank_bucket(): 0 = round robin, else tiles_x / world (diagonal deal)
     int rank, world;
     int sample_begin, sample_end;      // this call renders samples [sample_begin, sample_end) (rtk_render_params.sample_begin/_count)
 };
@@ -315,6 +316,7 @@ int frame_geom(const rtk_accel *a, const rtk_render_params *p, FrameGeom &g) {
     g.n_buckets = g.tiles_x * g.tiles_y;
     g.blocks_side = (g.bucket + 7) / 8;
     g.buckets_per_rank = (g.n_buckets + uint32_t(g.world) - 1) / uint32_t(g.world);
+    g.skew_q = (g.world > 1 && g.tiles_x % uint32_t(g.world) == 0u) ? g.tiles_x / uint32_t(g.world) : 0u;
     return RTK_OK;
 }
 
@@ -727,7 +729,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     A.shadow_bias = p->shadow_bias; A.reflection_bias = p->reflection_bias; A.refraction_bias = p->refraction_bias;
     A.bucket = g.bucket; A.tiles_x = g.tiles_x; A.tiles_y = g.tiles_y; A.n_buckets = g.n_buckets;
     A.blocks_per_bucket_side = g.blocks_side; A.buckets_per_rank = g.buckets_per_rank;
-    A.rank = g.rank; A.world = g.world; A.compact = g.world > 1 ? 1 : 0;
+    A.rank = g.rank; A.world = g.world; A.compact = g.world > 1 ? 1 : 0; A.skew_q = g.skew_q;
     A.out = d_out; A.counters = a->d_counters;
     A.slice_min_tris = a->knobs.slice_min_tris;
     const bool forks = a->has_refractive || p->diffuse_rays > 0;
@@ -918,7 +920,9 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     a->last_stats = p->collect_stats != 0;
     // primary rays of this rank: pixels of its buckets x spp
     uint64_t pixels = 0;
-    for (uint32_t b = uint32_t(g.rank); b < g.n_buckets; b += uint32_t(g.world)) {
+    for (uint32_t j = 0; j < g.buckets_per_rank; ++j) {
+        const uint32_t b = dev::rank_bucket(uint32_t(g.rank), j, uint32_t(g.world), g.skew_q);
+        if (b >= g.n_buckets) continue;
         const uint32_t bx = (b % g.tiles_x) * g.bucket, by = (b / g.tiles_x) * g.bucket;
         const uint32_t w = (bx + g.bucket <= g.width) ? g.bucket : g.width - bx;
         const uint32_t h = (by + g.bucket <= g.height) ? g.bucket : g.height - by;
@@ -997,7 +1001,7 @@ int rtk_tiles_assemble_device(const rtk_accel *a, const rtk_render_params *p, co
     if (!d_gathered || !d_rgb) return fail(RTK_ERR_INVALID, "null buffer");
     dev::AssembleArgs A;
     A.gathered = d_gathered; A.rgb = d_rgb; A.width = g.width; A.height = g.height; A.bucket = g.bucket;
-    A.tiles_x = g.tiles_x; A.world = uint32_t(g.world); A.buckets_per_rank = g.buckets_per_rank;
+    A.tiles_x = g.tiles_x; A.world = uint32_t(g.world); A.buckets_per_rank = g.buckets_per_rank; A.skew_q = g.skew_q;
     const hipError_t e = launch_assemble(A, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return hip_fail(e, "launch k_assemble");
     return RTK_OK;

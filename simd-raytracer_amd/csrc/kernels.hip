@@ -263,7 +263,7 @@ __global__ __launch_bounds__(SLICES > 1 ? 64 * SLICES : 256, SLICES == 16 ? 1 : 
     constexpr bool writer = true;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
     const uint32_t local_bucket = gwave / bpb, sub = gwave % bpb;
-    const uint32_t bucket = (uint32_t)A.rank + local_bucket * (uint32_t)A.world;
+    const uint32_t bucket = rank_bucket((uint32_t)A.rank, local_bucket, (uint32_t)A.world, A.skew_q);
     bool valid = bucket < A.n_buckets;
     const uint32_t bx = (bucket % A.tiles_x) * A.bucket, by = (bucket / A.tiles_x) * A.bucket;
     const uint32_t sub_x0 = (sub % A.blocks_per_bucket_side) * 8u, sub_y0 = (sub / A.blocks_per_bucket_side) * 8u;   // wave-uniform
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(64 * SLICES, 8) void k_primary(RenderArgs A) {
     const uint32_t gwave = blockIdx.x;
     const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
     const uint32_t local_bucket = gwave / bpb, sub = gwave % bpb;
-    const uint32_t bucket = (uint32_t)A.rank + local_bucket * (uint32_t)A.world;
+    const uint32_t bucket = rank_bucket((uint32_t)A.rank, local_bucket, (uint32_t)A.world, A.skew_q);
     const uint32_t bx = (bucket % A.tiles_x) * A.bucket, by = (bucket / A.tiles_x) * A.bucket;
     const uint32_t lx = (sub % A.blocks_per_bucket_side) * 8u + (lane & 7u);
     const uint32_t ly = (sub / A.blocks_per_bucket_side) * 8u + (lane >> 3);
@@ -826,7 +826,8 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs A) {
     if (i >= (size_t)A.width * A.height) return;
     const uint32_t px = (uint32_t)(i % A.width), py = (uint32_t)(i / A.width);
     const uint32_t bucket = (py / A.bucket) * A.tiles_x + (px / A.bucket);
-    const uint32_t rank = bucket % A.world, local = bucket / A.world;
+    uint32_t rank, local;
+    bucket_owner(bucket, A.tiles_x, A.world, A.skew_q, rank, local);
     const size_t src = (((size_t)rank * A.buckets_per_rank + local) * A.bucket + (py % A.bucket)) * A.bucket + (px % A.bucket);
     A.rgb[i * 3 + 0] = A.gathered[src * 3 + 0];
     A.rgb[i * 3 + 1] = A.gathered[src * 3 + 1];

@@ -23,6 +23,25 @@ constexpr size_t kMaxNodeLdsBytes = 48 * 1024;   // node arrays up to this size 
 namespace rtk {
 namespace dev {
 
+// Which rank renders which bucket (tile/bucket.hpp:7-21's row-major bucket list dealt to GPUs instead of threads).
+// Round robin: bucket i -> rank i % world, the i / world-th bucket of that rank.  When a row of buckets is a whole number of
+// rounds (tiles_x % world == 0: 3840 / 24 = 160 buckets per row on 8 ranks) round robin hands every rank the same COLUMNS of
+// every row, and a rank's share is as uneven as the picture is from left to right (config 5's shape: 32.8 M ... 38.9 M rays per
+// rank).  Those frames are dealt diagonally instead: bucket (bx, by) -> rank (bx + by) % world; with q = tiles_x / world buckets
+// per rank and row it is that rank's (by * q + bx / world)-th.  skew_q = q selects it (0 = round robin).  Host mirrors:
+// api.hip frame_geom / rank_bucket, parallel.py BucketLayout.
+__host__ __device__ inline uint32_t rank_bucket(uint32_t rank, uint32_t local, uint32_t world, uint32_t skew_q) {
+    if (skew_q == 0u) return rank + local * world;
+    const uint32_t by = local / skew_q, m = local % skew_q;
+    const uint32_t c0 = (rank + world - by % world) % world;
+    return by * (skew_q * world) + c0 + m * world;
+}
+__host__ __device__ inline void bucket_owner(uint32_t bucket, uint32_t tiles_x, uint32_t world, uint32_t skew_q, uint32_t &rank, uint32_t &local) {
+    if (skew_q == 0u) { rank = bucket % world; local = bucket / world; return; }
+    const uint32_t bx = bucket % tiles_x, by = bucket / tiles_x;
+    rank = (bx + by) % world; local = by * skew_q + bx / world;
+}
+
 struct IntersectArgs {
     TreeView tree;
     const rtk_ray *rays;
@@ -55,6 +74,7 @@ struct RenderArgs {
     // bucket sharding
     uint32_t bucket, tiles_x, tiles_y, n_buckets, blocks_per_bucket_side;
     uint32_t buckets_per_rank;
+    uint32_t skew_q;                  // rank_bucket(): 0 = buckets dealt round robin, else diagonally with tiles_x / world per rank and row
     int rank, world;
     uint32_t slice_min_tris;          // GROUP modes: smallest leaf that is split across the workgroup's waves
     int compact;                      // 1: out is [buckets_per_rank][bucket][bucket][3]; 0: out is [h][w][3]
@@ -88,7 +108,7 @@ struct RenderArgs {
 struct AssembleArgs {
     const float *gathered;
     float *rgb;
-    uint32_t width, height, bucket, tiles_x, world, buckets_per_rank;
+    uint32_t width, height, bucket, tiles_x, world, buckets_per_rank, skew_q;
 };
 
 }  // namespace dev

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
         if (LEVEL0) {
             const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
             const uint32_t local_bucket = item / bpb, sub = item % bpb;
-            const uint32_t bucket = (uint32_t)A.rank + local_bucket * (uint32_t)A.world;
+            const uint32_t bucket = rank_bucket((uint32_t)A.rank, local_bucket, (uint32_t)A.world, A.skew_q);
             const uint32_t bx = (bucket % A.tiles_x) * A.bucket, by = (bucket / A.tiles_x) * A.bucket;
             const uint32_t lx = (sub % A.blocks_per_bucket_side) * 8u + (lane & 7u);
             const uint32_t ly = (sub / A.blocks_per_bucket_side) * 8u + (lane >> 3);

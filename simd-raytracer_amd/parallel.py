@@ -2,7 +2,8 @@
 
 The reference's only parallelism is threads pulling bucket tiles from a mutex queue
 (render/tile/bucket.hpp:7-21, render/tile/queue.hpp:30-41, render/render.hpp:93-101).  Here bucket i belongs to
-rank i % world (interleaved, because coverage is very uneven: most of scene5 is background); every rank renders
+rank i % world (interleaved, because coverage is very uneven: most of scene5 is background; diagonally, bucket (bx, by) ->
+rank (bx + by) % world, when a row of buckets is a whole number of rounds -- BucketLayout.skew_q); every rank renders
 its buckets into a compact [buckets_per_rank, bucket, bucket, 3] buffer of equal length, the buffers are
 all-gathered, and every rank assembles the frame.  No other collective is needed: pixels are independent and
 the RNG is keyed by absolute pixel, so the frame does not depend on the number of ranks.
@@ -44,15 +45,35 @@ class BucketLayout:
     def floats_per_rank(self) -> int:
         return self.buckets_per_rank * self.bucket * self.bucket * 3
 
-    def buckets_of(self, rank: int) -> range:
-        return range(rank, self.n_buckets, self.world)
+    @property
+    def skew_q(self) -> int:
+        """csrc/kernels.hpp rank_bucket(): when a row of buckets is a whole number of rounds (tiles_x % world == 0) round robin
+        would give every rank the same columns of every row; those frames are dealt diagonally, bucket (bx, by) -> rank
+        (bx + by) % world, tiles_x / world buckets per rank and row.  0 = plain round robin (bucket i -> rank i % world)."""
+        return self.tiles_x // self.world if (self.world > 1 and self.tiles_x % self.world == 0) else 0
+
+    def buckets_of(self, rank: int) -> list:
+        """The buckets (row-major indices) of `rank`, in the order of its compact buffer."""
+        q = self.skew_q
+        if q == 0:
+            return list(range(rank, self.n_buckets, self.world))
+        out = []
+        for local in range(self.buckets_per_rank):
+            by, m = divmod(local, q)
+            out.append(by * self.tiles_x + (rank - by) % self.world + m * self.world)
+        return out
 
     def pixel_sources(self) -> torch.Tensor:
         """For every frame pixel, its index in the gathered [world, buckets_per_rank, bucket, bucket] array."""
         ys = torch.arange(self.height).view(-1, 1)
         xs = torch.arange(self.width).view(1, -1)
-        b = (ys // self.bucket) * self.tiles_x + (xs // self.bucket)
-        rank, local = b % self.world, b // self.world
+        bx, by = xs // self.bucket, ys // self.bucket
+        q = self.skew_q
+        if q == 0:
+            b = by * self.tiles_x + bx
+            rank, local = b % self.world, b // self.world
+        else:
+            rank, local = (bx + by) % self.world, by * q + bx // self.world
         return ((rank * self.buckets_per_rank + local) * self.bucket + ys % self.bucket) * self.bucket + xs % self.bucket
 
 
@@ -133,6 +154,7 @@ class FramePipeline:
         self._render = render or self._render_device
         self._assemble = assemble or self._assemble_device
         self._pending = collections.deque()
+        self._last = None
         self.submitted = 0
 
     def _render_device(self, local: torch.Tensor, k: int) -> None:
@@ -157,7 +179,12 @@ class FramePipeline:
         k, slot, work = self._pending.popleft()
         work.wait()                       # device tensors: the compute stream waits, the host does not
         self._assemble(self.gathered[slot], self.frames[slot])
+        self._last = self.frames[slot]
         return k, self.frames[slot]
+
+    def last_frame(self) -> torch.Tensor:
+        """The frame retired last (assembled on this rank)."""
+        return self._last
 
     def drain(self):
         """Retires every frame still in flight, oldest first."""

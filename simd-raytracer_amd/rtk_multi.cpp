@@ -1,4 +1,4 @@
-// Multi-GPU frames from C++: one process per GPU, buckets dealt round-robin to the ranks (bucket i -> rank i % world, the
+// Multi-GPU frames from C++: one process per GPU, buckets dealt round-robin to the ranks (bucket i -> rank i % world; diagonally when tiles_x % world == 0, see rtk.h; the
 // reference's bucket_schedule, render/tile/bucket.hpp:7-21, spread over GPUs instead of threads), ONE collective -- an RCCL
 // all-gather of the rank-local bucket buffers over xGMI -- and rtk_tiles_assemble_device on every rank.  This is the C++
 // twin of simd-raytracer_amd/parallel.py; the engine library itself (librtk_hip.so) stays free of RCCL.

@@ -335,14 +335,17 @@ def test_full_size_properties_4k(rtk, ora):
     assert np.array_equal(_bits(out.cpu().numpy()), _bits(base))
 
 
-@pytest.mark.parametrize("scene,w,h,world", [("scene5", 640, 360, 2), ("hw15_scene2", 200, 200, 4), ("scene8", 333, 77, 8)])
-def test_sharded_frames_assemble_to_the_unsharded_frame(rtk, ora, scene, w, h, world):
+@pytest.mark.parametrize("scene,w,h,world", [("scene5", 640, 360, 2), ("hw15_scene2", 200, 200, 4), ("scene8", 333, 77, 8),
+                                             # whole rounds of buckets per row: the diagonal deal (kernels.hpp rank_bucket)
+                                             ("hw15_scene2", 192, 120, 8), ("scene5", 512, 300, 4), ("hw15_scene2", 96, 96, 2)])
+@pytest.mark.parametrize("mode", [0, 6])
+def test_sharded_frames_assemble_to_the_unsharded_frame(rtk, ora, scene, w, h, world, mode):
     import torch
 
     acc, _ = _scene_pair(rtk, ora, CONFIG_SCENES[scene])
     depth = 10 if scene == "scene8" else 5
     base, cn = acc.render_frame(rtk.RenderConfig(width=w, height=h, max_ray_depth=depth))
-    cfgs = [rtk.RenderConfig(width=w, height=h, max_ray_depth=depth, rank=r, world_size=world) for r in range(world)]
+    cfgs = [rtk.RenderConfig(width=w, height=h, max_ray_depth=depth, rank=r, world_size=world, trace_mode=mode) for r in range(world)]
     n = acc.output_floats(cfgs[0])
     gathered = torch.full((world, n), float("nan"), dtype=torch.float32, device="cuda")
     rays = 0
