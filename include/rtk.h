@@ -127,7 +127,20 @@ typedef struct {
     float eps;                      /* 1e-6f  (config.hpp:8) */
     int32_t normalize_hit_normal;   /* 1 = kd_tree_simd.hpp:250 behaviour, 0 = kd_tree.hpp:140 behaviour */
     int32_t device;                 /* HIP device ordinal; -1 = current device */
+    int32_t traversal;              /* RTK_TRAVERSAL_* ; 0 = the reference's order (the parity mode, default) */
 } rtk_accel_params;
+
+/* Leaf visiting order of the wave-cooperative walks (kd_tree_simd.hpp:207-214 pushes child0 then child1 for every ray: child1
+ * is always visited first, there is no near/far ordering; README.md:118-124 lists better traversal as the author's to-do).
+ *   RTK_TRAVERSAL_REFERENCE  that order: every result bit-identical to the reference (hit-record ties included).
+ *   RTK_TRAVERSAL_FAST       front to back: at every split plane the child on the side the rays come from is visited first
+ *                            (chosen per wave from the majority sign of the direction on each axis), so a hit found early
+ *                            prunes what lies behind it (`best_t < box.t_min`, :203-205).  The closest distance t of every
+ *                            ray is unchanged; which of several triangles with EXACTLY that t wins (shared edges and vertices,
+ *                            duplicated references) may differ, and with it u, v, the triangle index and the normal of such hits.
+ *                            Occlusion queries give the same answers.  Not the parity mode: off unless asked for here, or by
+ *                            RTK_TRAVERSAL_FAST=1 in the environment when the accel is built. */
+enum { RTK_TRAVERSAL_REFERENCE = 0, RTK_TRAVERSAL_FAST = 1 };
 
 typedef struct {
     int32_t n_nodes, n_inner, n_leaves;

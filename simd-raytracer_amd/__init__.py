@@ -26,6 +26,7 @@ RTK_OK, RTK_ERR_INVALID, RTK_ERR_NO_DEVICE, RTK_ERR_HIP, RTK_ERR_IO, RTK_ERR_PAR
 MAT_DIFFUSE, MAT_REFLECTIVE, MAT_REFRACTIVE, MAT_CONSTANT, MAT_TEXTURE = 0, 1, 2, 3, 4
 TEX_ALBEDO, TEX_EDGES, TEX_CHECKER, TEX_BITMAP = 0, 1, 2, 3
 TRACE_AUTO, TRACE_LANE, TRACE_WAVE, TRACE_GROUP4, TRACE_GROUP8, TRACE_GROUP16, TRACE_STREAM, TRACE_TWOPASS = 0, 1, 2, 3, 4, 5, 6, 7
+TRAVERSAL_REFERENCE, TRAVERSAL_FAST = 0, 1     # rtk.h RTK_TRAVERSAL_*: leaf order of the wave-cooperative walks (FAST is not the parity mode)
 TRACE_REPACK = 8        # batched intersect only: rays sorted by origin / direction cell before the trace (csrc/repack.hip)
 
 # every symbol include/rtk.h declares (checked by tests/test_abi.py)
@@ -91,7 +92,7 @@ class SceneInfo(C.Structure):
 
 class AccelParams(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("max_leaf_size", C.c_int32), ("eps", C.c_float),
-                ("normalize_hit_normal", C.c_int32), ("device", C.c_int32)]
+                ("normalize_hit_normal", C.c_int32), ("device", C.c_int32), ("traversal", C.c_int32)]
 
 
 class TreeInfo(C.Structure):
@@ -323,9 +324,9 @@ class KdTreeSimdAccel:
     normalize_hit_normal=False gives kd_tree_accel's un-normalised hit_normal (kd_tree.hpp:140)."""
 
     def __init__(self, scene: Scene, eps: float = 1e-6, max_depth: int = 8, max_leaf_size: int = 64,
-                 normalize_hit_normal: bool = True, device: int = -1):
+                 normalize_hit_normal: bool = True, device: int = -1, traversal: int = TRAVERSAL_REFERENCE):
         self.scene = scene  # the reference keeps scene_ptr public (render.hpp:21)
-        p = AccelParams(max_depth, max_leaf_size, np.float32(eps), 1 if normalize_hit_normal else 0, device)
+        p = AccelParams(max_depth, max_leaf_size, np.float32(eps), 1 if normalize_hit_normal else 0, device, traversal)
         h = _vp()
         _check(_L.rtk_accel_build(scene._h, C.byref(p), C.byref(h)))
         self._h = h

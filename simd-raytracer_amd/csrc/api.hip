@@ -67,7 +67,11 @@ struct rtk_knobs {
     int stream_sort_from = -1;                              // RTK_STREAM_SORT_FROM (-1 = default)
     bool stream_debug = false;                              // RTK_STREAM_DEBUG
     bool stream_side = true;                                // RTK_STREAM_SIDE: k_shadow on side streams
-    int stream_lanes = 4;                                   // RTK_STREAM_LANES: samples of a frame in flight at once (1..kStreamLanes); 8 measured no faster
+    int stream_lanes = 4;                                   // RTK_STREAM_LANES: batches of a frame in flight at once (1..kStreamLanes); 8 measured no faster
+    int stream_batch = 1;                                   // RTK_STREAM_BATCH: samples traced together per launch (stream.hpp)
+    int stream_mem_gb = 96;                                 // RTK_STREAM_MEM_GB: budget for the queues of all batches in flight
+    int stream_side_below = 2;                              // RTK_STREAM_SIDE_BELOW: k_shadow on side streams while at most this many samples are in flight
+    bool traversal_fast = false;                            // RTK_TRAVERSAL_FAST: front-to-back leaf order (rtk.h; NOT the parity mode)
 
     static rtk_knobs from_env() {
         rtk_knobs k;
@@ -93,6 +97,10 @@ struct rtk_knobs {
         if (geti("RTK_STREAM_SORT_FROM", v)) k.stream_sort_from = int(v);
         if (geti("RTK_STREAM_DEBUG", v)) k.stream_debug = v != 0;
         if (geti("RTK_STREAM_SIDE", v)) k.stream_side = v != 0;
+        if (geti("RTK_TRAVERSAL_FAST", v)) k.traversal_fast = v != 0;
+        if (geti("RTK_STREAM_BATCH", v) && v >= 1 && v <= 4096) k.stream_batch = int(v);
+        if (geti("RTK_STREAM_MEM_GB", v) && v >= 1 && v <= 256) k.stream_mem_gb = int(v);
+        if (geti("RTK_STREAM_SIDE_BELOW", v) && v >= 0) k.stream_side_below = int(v);
         if (geti("RTK_STREAM_LANES", v) && v >= 1 && v <= rtk::dev::kStreamLanes) k.stream_lanes = int(v);
         return k;
     }
@@ -110,6 +118,8 @@ struct rtk_accel {
     int device = -1;
     rtk::DevNode *d_nodes = nullptr;
     rtk::DevNode *d_leaves = nullptr;
+    rtk::DevNode *d_leaves_fast = nullptr;    // RTK_TRAVERSAL_FAST: 8 front-to-back orders of the leaves (null in the parity mode)
+    bool fast_traversal = false;
     rtk::DevTri *d_tris = nullptr;
     uint32_t *d_tri_ids = nullptr;
     rtk::DevShade *d_shade = nullptr;
@@ -179,6 +189,7 @@ int ensure_device(rtk_accel *a) {
     int rc;
     if ((rc = upload(a->tree.dev_nodes, &a->d_nodes)) != RTK_OK) return rc;
     if ((rc = upload(a->tree.dev_leaves, &a->d_leaves)) != RTK_OK) return rc;
+    if (a->fast_traversal && (rc = upload(a->tree.dev_leaves_fast, &a->d_leaves_fast)) != RTK_OK) return rc;
     if ((rc = upload(a->tree.dev_tris, &a->d_tris)) != RTK_OK) return rc;
     if ((rc = upload(a->tree.dev_tri_ids, &a->d_tri_ids)) != RTK_OK) return rc;
     if ((rc = upload(a->tree.dev_shade, &a->d_shade)) != RTK_OK) return rc;
@@ -199,6 +210,7 @@ dev::TreeView tree_view(const rtk_accel *a) {
     dev::TreeView t;
     t.nodes = a->d_nodes; t.tris = a->d_tris; t.tri_ids = a->d_tri_ids; t.shade = a->d_shade;
     t.leaves = a->d_leaves; t.n_leaves = static_cast<uint32_t>(a->tree.dev_leaves.size());
+    t.leaves_fast = a->fast_traversal ? a->d_leaves_fast : nullptr;
     t.n_nodes = static_cast<uint32_t>(a->tree.dev_nodes.size());
     t.eps = a->params.eps;
     t.normalize = a->params.normalize_hit_normal;
@@ -484,7 +496,8 @@ int rtk_accel_build(const rtk_scene *scene, const rtk_accel_params *params, rtk_
         rtk_accel *a = new rtk_accel();
         a->scene = *scene;
         if (params) a->params = *params;
-        else { a->params.max_depth = 8; a->params.max_leaf_size = 64; a->params.eps = 1e-6f; a->params.normalize_hit_normal = 1; a->params.device = -1; }
+        else { a->params.max_depth = 8; a->params.max_leaf_size = 64; a->params.eps = 1e-6f; a->params.normalize_hit_normal = 1; a->params.device = -1; a->params.traversal = RTK_TRAVERSAL_REFERENCE; }
+        if (a->params.traversal != RTK_TRAVERSAL_REFERENCE && a->params.traversal != RTK_TRAVERSAL_FAST) { delete a; return fail(RTK_ERR_INVALID, "unknown traversal"); }
         std::string err;
         const int rc = build_tree(a->scene, a->params.max_depth, a->params.max_leaf_size, a->tree, err);
         if (rc != RTK_OK) { delete a; return fail(rc, err); }
@@ -498,6 +511,8 @@ int rtk_accel_build(const rtk_scene *scene, const rtk_accel_params *params, rtk_
         }
         for (const DevMaterial &m : a->scene.materials) if (m.kind == RTK_MAT_REFRACTIVE) a->has_refractive = true;
         a->knobs = rtk_knobs::from_env();
+        a->fast_traversal = a->params.traversal == RTK_TRAVERSAL_FAST || a->knobs.traversal_fast;
+        if (a->fast_traversal) build_fast_leaf_orders(a->tree);
         a->coords_small = true;
         for (const DevTri &t : a->tree.dev_tris)
             for (int k = 0; k < 3; ++k)
@@ -546,7 +561,7 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipSetDevice(a->device);
         (void)hipFree(a->d_nodes); (void)hipFree(a->d_leaves); (void)hipFree(a->d_tris); (void)hipFree(a->d_tri_ids); (void)hipFree(a->d_shade);
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
-        (void)hipFree(a->d_textures); (void)hipFree(a->d_tri_uv); (void)hipFree(a->d_tex_pixels);
+        (void)hipFree(a->d_textures); (void)hipFree(a->d_tri_uv); (void)hipFree(a->d_tex_pixels); (void)hipFree(a->d_leaves_fast);
         free_stream_ws(a);
         for (auto &st : a->lane_stream) if (st) (void)hipStreamDestroy(st);
         for (auto &e : a->lane_done) if (e) (void)hipEventDestroy(e);
@@ -799,12 +814,22 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         // redone by the megakernel.
         const size_t factor = a->knobs.stream_node_factor > 0 ? size_t(a->knobs.stream_node_factor) : (forks ? 8 : 3);
         const int n_pass = g.sample_end - g.sample_begin;
-        const int lanes = n_pass < a->knobs.stream_lanes ? n_pass : a->knobs.stream_lanes;     // samples in flight at once (stream.hpp)
-        rc = ensure_stream_ws(a, out_pixels, n_root * factor + 4096, a->scene.lights.size(), p->spp > 1, lanes);
+        // Samples per launch (stream.hpp "batch") and batches in flight.  A batch's queues cost ~120 B per ray-tree node: the
+        // batch is as large as the pass, the knob and the memory budget allow (288 GB of HBM is what this design spends).
+        const size_t nodes_per_sample = n_root * factor + 4096;
+        const size_t bytes_per_node = sizeof(dev::RayRec) + sizeof(dev::NodeRes) + sizeof(uint32_t) +
+                                      (sizeof(dev::HitRec) + sizeof(uint32_t) + sizeof(float2) * (a->scene.lights.empty() ? 1 : a->scene.lights.size())) / 2 + 1;
+        int batch = n_pass < a->knobs.stream_batch ? n_pass : a->knobs.stream_batch;
+        const size_t budget = size_t(a->knobs.stream_mem_gb) << 30;
+        while (batch > 1 && (nodes_per_sample * size_t(batch) > 0xF0000000ull || nodes_per_sample * size_t(batch) * bytes_per_node > budget)) batch -= 1;
+        const int n_launch = (n_pass + batch - 1) / batch;
+        int lanes = n_launch < a->knobs.stream_lanes ? n_launch : a->knobs.stream_lanes;     // batches in flight at once (stream.hpp)
+        while (lanes > 1 && nodes_per_sample * size_t(batch) * bytes_per_node * size_t(lanes) > budget) lanes -= 1;
+        rc = ensure_stream_ws(a, out_pixels, nodes_per_sample * size_t(batch), a->scene.lights.size(), p->spp > 1, lanes);
         if (rc != RTK_OK) return rc;
         dev::StreamArgs S;
         S.r = A; S.r.tree.scalar_surv = a->knobs.stream_scalar_surv ? 1 : 0; S.ws = a->ws;
-        S.key_dirs = p->diffuse_rays > 0 ? 1u : 0u; S.level = 0; S.sample = 0; S.n_root = uint32_t(n_root); S.auto_min_lanes = a->knobs.auto_min_lanes;
+        S.key_dirs = p->diffuse_rays > 0 ? 1u : 0u; S.level = 0; S.sample = 0; S.n_batch = 1; S.n_root = uint32_t(n_root); S.n_level0 = uint32_t(n_root); S.auto_min_lanes = a->knobs.auto_min_lanes;
         S.n_lanes = uint32_t(lanes);
         for (int j = 0; j < dev::kStreamLanes; ++j) S.lane_overflow[j] = a->ws_lane[j < lanes ? j : 0].ctrl + dev::kCtrlOverflow;
         // measured on MI355X: the workgroup-cooperative wave walk beats the per-lane walk at every depth, even for the
@@ -827,17 +852,19 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             RTK_HIP(hipEventRecord(a->lane_fork, s));
             for (int j = 1; j < lanes; ++j) RTK_HIP(hipStreamWaitEvent(a->lane_stream[j], a->lane_fork, 0));
         }
-        for (int sample = g.sample_begin; sample < g.sample_end; ++sample) {
-            const int i = sample - g.sample_begin, j = i % lanes;
-            S.sample = sample;
+        for (int i = 0; i < n_launch; ++i) {
+            const int j = i % lanes;
+            S.sample = g.sample_begin + i * batch;
+            S.n_batch = uint32_t(g.sample_end - S.sample < batch ? g.sample_end - S.sample : batch);
+            S.n_level0 = uint32_t(n_root) * S.n_batch;
             S.ws = a->ws_lane[j];
             const hipStream_t ls = j == 0 ? s : a->lane_stream[j];
             const hipEvent_t wait = (lanes > 1 && i > 0) ? a->lane_done[(i - 1) % lanes] : nullptr;
             const hipEvent_t done = lanes > 1 ? a->lane_done[j] : nullptr;
             const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, deep_level, deep_mode, sort_from, ls, wait, done,
-                                                       // (side streams help while few samples are in flight: spp 1 16.7 -> 9.1 ms on config 3;
+                                                       // (side streams help while few rays are in flight: spp 1 16.7 -> 9.1 ms on config 3;
                                                        // with four lanes the GPU is full already and they cost 20 %)
-                                                       (a->knobs.stream_side && lanes <= 2) ? &a->lane_side[j] : nullptr);
+                                                       (a->knobs.stream_side && lanes <= 2 && batch * lanes <= a->knobs.stream_side_below) ? &a->lane_side[j] : nullptr);
             if (es != hipSuccess) return hip_fail(es, "launch streaming pipeline");
         }
         // join: the caller's stream continues behind the last sample of every lane

@@ -114,7 +114,47 @@ void flatten(HostTree &t, int32_t node) {
     t.dev_nodes[at].a = uint32_t(t.dev_nodes.size());                  // skip = first node after this subtree
 }
 
+// RTK_TRAVERSAL_FAST: the leaves of the subtree of `node`, front to back for rays of direction octant `oct`.  The children
+// of a node are the halves of its box on either side of one axis-aligned plane (aabb3::split, aabb3.hpp:43-60: child0 below,
+// child1 above), so which half a ray passes first depends on the sign of its direction on that axis alone.
+void leaves_front_to_back(const HostTree &t, int32_t node, unsigned oct, std::vector<DevNode> &out, const std::vector<uint32_t> &leaf_slot) {
+    const HostNode &hn = t.nodes[size_t(node)];
+    if (hn.leaf_start >= 0) { out.push_back(t.dev_leaves[leaf_slot[size_t(node)]]); return; }
+    int axis = 0;
+    if (hn.child0 >= 0) {
+        const Box &c = t.nodes[size_t(hn.child0)].box;
+        axis = c.mx.x != hn.box.mx.x ? 0 : (c.mx.y != hn.box.mx.y ? 1 : 2);
+    } else if (hn.child1 >= 0) {
+        const Box &c = t.nodes[size_t(hn.child1)].box;
+        axis = c.mn.x != hn.box.mn.x ? 0 : (c.mn.y != hn.box.mn.y ? 1 : 2);
+    }
+    const bool downwards = ((oct >> axis) & 1u) != 0u;
+    const int32_t first = downwards ? hn.child1 : hn.child0, second = downwards ? hn.child0 : hn.child1;
+    if (first >= 0) leaves_front_to_back(t, first, oct, out, leaf_slot);
+    if (second >= 0) leaves_front_to_back(t, second, oct, out, leaf_slot);
+}
+
 }  // namespace
+
+void build_fast_leaf_orders(HostTree &t) {
+    // where each leaf node went in dev_leaves: replay flatten's order (node, child1 subtree, child0 subtree)
+    std::vector<uint32_t> leaf_slot(t.nodes.size(), 0u);
+    {
+        uint32_t next = 0;
+        std::vector<int32_t> stack{0};
+        while (!stack.empty()) {
+            const int32_t n = stack.back();
+            stack.pop_back();
+            const HostNode &hn = t.nodes[size_t(n)];
+            if (hn.leaf_start >= 0) { leaf_slot[size_t(n)] = next++; continue; }
+            if (hn.child0 >= 0) stack.push_back(hn.child0);          // popped second
+            if (hn.child1 >= 0) stack.push_back(hn.child1);          // popped first
+        }
+    }
+    t.dev_leaves_fast.clear();
+    t.dev_leaves_fast.reserve(t.dev_leaves.size() * 8);
+    for (unsigned oct = 0; oct < 8u; ++oct) leaves_front_to_back(t, 0, oct, t.dev_leaves_fast, leaf_slot);
+}
 
 int build_tree(const rtk_scene &scene, int max_depth, int max_leaf, HostTree &out, std::string &err) {
     if (max_depth < 0 || max_depth > 24) { err = "max_depth must be in [0, 24]"; return RTK_ERR_INVALID; }

@@ -864,7 +864,10 @@ template <int MODE, bool STATS>
 hipError_t launch_intersect_m(const dev::IntersectArgs &A, bool lds, size_t lds_bytes, hipStream_t s) {
     const unsigned blocks = (unsigned)((A.n + 255) / 256);
     if (blocks == 0) return hipSuccess;
-    if (lds) hipLaunchKernelGGL((dev::k_intersect<MODE, STATS, true>), dim3(blocks), dim3(256), lds_bytes, s, A);
+    // only the per-lane walk reads the node array from LDS: the wave-cooperative one fetches nodes and leaves through the scalar
+    // cache (staging the array for it copied 6 KB per 256 rays for nothing)
+    constexpr bool kNeedsNodes = (MODE == RTK_TRACE_LANE || MODE == RTK_TRACE_AUTO);
+    if (lds && kNeedsNodes) hipLaunchKernelGGL((dev::k_intersect<MODE, STATS, true>), dim3(blocks), dim3(256), lds_bytes, s, A);
     else hipLaunchKernelGGL((dev::k_intersect<MODE, STATS, false>), dim3(blocks), dim3(256), 0, s, A);
     return hipGetLastError();
 }

@@ -129,6 +129,8 @@ struct HostTree {
     // device-order flattening
     std::vector<DevNode> dev_nodes;
     std::vector<DevNode> dev_leaves;           // the leaves of dev_nodes alone, same order (leaf-list traversal, trace.hip.hpp)
+    std::vector<DevNode> dev_leaves_fast;      // RTK_TRAVERSAL_FAST: [8][n_leaves] the same leaves front to back for each direction octant
+                                               // (bit a of the octant set = rays travel towards smaller coordinates on axis a)
     std::vector<DevTri> dev_tris;
     std::vector<uint32_t> dev_tri_ids;         // leaf-ref -> global triangle index
     std::vector<DevShade> dev_shade;           // per global triangle
@@ -145,6 +147,7 @@ int decode_jpeg(const uint8_t *data, size_t size, int &width, int &height, int &
 int load_bitmap_file(const std::string &path, int &width, int &height, int &channels, std::vector<uint8_t> &pixels, std::string &err);
 // kdtree.cpp
 int build_tree(const rtk_scene &scene, int max_depth, int max_leaf, HostTree &out, std::string &err);
+void build_fast_leaf_orders(HostTree &tree);          // fills dev_leaves_fast (RTK_TRAVERSAL_FAST)
 // ppm.cpp
 std::string format_ppm(const float *rgb, int width, int height);
 std::string format_ppm_rgb8(const uint8_t *rgb8, int width, int height);

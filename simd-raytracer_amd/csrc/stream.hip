@@ -110,30 +110,6 @@ __device__ __forceinline__ void level_range(const uint32_t *count_words, const u
     count = (b + c <= cap) ? (uint32_t)c : cap - base;
 }
 
-// final_color += colour ; after the last sample: pixels[y][x] = final_color / spp   (render.hpp:66-74)
-__device__ __forceinline__ void emit_pixel(const StreamArgs &S, const uint32_t pix, const V3 ret) {
-    // The running sum of a pixel lives in ws.sumbuf between the samples of one pass and in the output buffer between the
-    // passes of a progressive frame (rtk_render_params.sample_begin); the sum stays in sample order either way.
-    V3 sum;
-    if (S.sample == 0) sum = mk(0.0f + ret.x, 0.0f + ret.y, 0.0f + ret.z);
-    else {
-        const float *sb = (S.sample == S.r.sample_begin ? S.r.out : S.ws.sumbuf) + (size_t)pix * 3;
-        sum = mk(sb[0] + ret.x, sb[1] + ret.y, sb[2] + ret.z);
-    }
-    if (S.sample == S.r.sample_end - 1) {
-        float *o = S.r.out + (size_t)pix * 3;
-        if (S.r.sample_end == S.r.spp) {
-            const float n = (float)S.r.spp;
-            o[0] = sum.x / n; o[1] = sum.y / n; o[2] = sum.z / n;
-        } else {
-            o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
-        }
-    } else {
-        float *sb = S.ws.sumbuf + (size_t)pix * 3;
-        sb[0] = sum.x; sb[1] = sum.y; sb[2] = sum.z;
-    }
-}
-
 __device__ __forceinline__ void add_rays(const StreamArgs &S, const Stats &st, const uint32_t rays, const bool stats,
                                          const uint32_t shard) {
     const uint32_t total = wave_sum(rays);
@@ -229,7 +205,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
         return;
     }
     uint32_t base, count;
-    level_range(ctrl + kCtrlNodeCount, S.n_root, level, S.ws.node_cap, base, count);
+    level_range(ctrl + kCtrlNodeCount, S.n_level0, level, S.ws.node_cap, base, count);
     const uint32_t next_base = base + count;                                  // where depth level+1 starts
     uint32_t hit_base = 0u;
     for (uint32_t j = 0; j < level; ++j) hit_base += ctrl[kCtrlHitCount + j];
@@ -256,7 +232,9 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
         Ray ray;
         if (LEVEL0) {
             const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
-            const uint32_t local_bucket = item / bpb, sub = item % bpb;
+            const uint32_t n_blocks = S.n_root >> 6;                           // items [b * n_blocks, (b + 1) * n_blocks): sample b of the batch
+            const uint32_t blk = item % n_blocks, in_batch = item / n_blocks;
+            const uint32_t local_bucket = blk / bpb, sub = blk % bpb;
             const uint32_t bucket = rank_bucket((uint32_t)A.rank, local_bucket, (uint32_t)A.world, A.skew_q);
             const uint32_t bx = (bucket % A.tiles_x) * A.bucket, by = (bucket / A.tiles_x) * A.bucket;
             const uint32_t lx = (sub % A.blocks_per_bucket_side) * 8u + (lane & 7u);
@@ -264,7 +242,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
             const uint32_t px = bx + lx, py = by + ly;
             valid = valid & (bucket < A.n_buckets) & (lx < A.bucket) & (ly < A.bucket) & (px < A.width) & (py < A.height);
             if (valid) pix = (uint32_t)A.out_index(local_bucket, lx, ly, px, py);
-            key = root_key(pcg_hash(A.seed), py * A.width + px, (uint32_t)S.sample);
+            key = root_key(pcg_hash(A.seed), py * A.width + px, (uint32_t)S.sample + in_batch);
             ray = camera_ray(A, px, py, key);
         } else {
             const float4 *q = reinterpret_cast<const float4 *>(S.ws.rays + node);
@@ -541,7 +519,7 @@ __device__ __forceinline__ uint32_t bin_slot(uint32_t *bins, const uint32_t key,
 __global__ __launch_bounds__(256) void k_sort_scatter_nodes(StreamArgs S) {
     if (S.ws.ctrl[kCtrlOverflow] != 0u) return;
     uint32_t base, count;
-    level_range(S.ws.ctrl + kCtrlNodeCount, S.n_root, S.level, S.ws.node_cap, base, count);
+    level_range(S.ws.ctrl + kCtrlNodeCount, S.n_level0, S.level, S.ws.node_cap, base, count);
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < count; i0 += stride) {           // (whole waves stay in the loop: bin_slot is wave-wide)
         const uint32_t i = i0 + threadIdx.x;
@@ -573,55 +551,100 @@ __global__ __launch_bounds__(256) void k_sort_scatter_hits(StreamArgs S) {
 
 // ------------------------------------------------------------------------------------------------
 // k_combine: one thread per depth-`level` node.  Children (depth level+1) are final by now.
-__global__ __launch_bounds__(256) void k_combine(StreamArgs S) {
+// The value of node `nd` from its children, in the recursion's operation order (stored back for inner nodes).
+__device__ __forceinline__ V3 combine_node(const StreamArgs &S, NodeRes *nd, uint32_t &pix) {
     const RenderArgs &A = S.r;
+    const uint32_t n_lights = (uint32_t)A.n_lights;
+    const float4 *q = reinterpret_cast<const float4 *>(nd);
+    const float4 a = q[0], b = q[1];
+    const uint32_t kind = __float_as_uint(a.w), first = __float_as_uint(b.x), aux = __float_as_uint(b.y),
+                   nchild = __float_as_uint(b.z);
+    pix = __float_as_uint(b.w);
+    V3 v = mk(a.x, a.y, a.z);
+    if (kind == NODE_PASS) {                                               // render.hpp:249 / :275
+        const NodeRes *c = S.ws.nodes + first;
+        v = mk(c->value[0], c->value[1], c->value[2]);
+    } else if (kind == NODE_REFR) {                                        // :301
+        const NodeRes *c0 = S.ws.nodes + first, *c1 = c0 + 1;
+        const float fresnel = __uint_as_float(aux);
+        const V3 refr = mk(c0->value[0], c0->value[1], c0->value[2]), refl = mk(c1->value[0], c1->value[1], c1->value[2]);
+        v = (fresnel * refl) + ((1.0f - fresnel) * refr);
+    } else if (kind == NODE_TEX) {                                         // :211-238
+        V3 acc = mk(0.f, 0.f, 0.f);
+        for (uint32_t k = 0; k < n_lights; ++k) {
+            const float2 cv = S.ws.contrib[(size_t)aux * n_lights + k];
+            if (cv.y != 0.0f) acc = acc + (cv.x * v);                      // v still holds the sampled texture colour
+        }
+        v = acc;
+    } else if (kind == NODE_DIFF) {                                        // :151-208
+        const HitRec *h = S.ws.hits + aux;
+        const DevMaterial *m = A.materials + h->mat;
+        const V3 albedo = mk(m->albedo[0], m->albedo[1], m->albedo[2]);
+        V3 acc = mk(0.f, 0.f, 0.f);
+        for (uint32_t g = 0; g < nchild; ++g) {                            // a GI ray that missed is worth 0: adding it changes nothing
+            const NodeRes *c = S.ws.nodes + first + g;
+            acc = acc + mk(c->value[0], c->value[1], c->value[2]);
+        }
+        for (uint32_t k = 0; k < n_lights; ++k) {
+            const float2 cv = S.ws.contrib[(size_t)aux * n_lights + k];
+            if (cv.y != 0.0f) acc = acc + (cv.x * albedo);
+        }
+        const float div = (float)(A.diffuse_rays + 1);
+        v = mk(acc.x / div, acc.y / div, acc.z / div);
+    }
+    if (kind != NODE_LEAF) { nd->value[0] = v.x; nd->value[1] = v.y; nd->value[2] = v.z; }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_combine(StreamArgs S) {
     if (S.ws.ctrl[kCtrlOverflow] != 0u) return;                                // the megakernel redoes the frame
     if (S.level == 0u)                                                         // pixels are only touched while no sample of the frame has overflowed
         for (uint32_t j = 0; j < S.n_lanes; ++j) if (*S.lane_overflow[j] != 0u) return;
     uint32_t base, count;
-    level_range(S.ws.ctrl + kCtrlNodeCount, S.n_root, S.level, S.ws.node_cap, base, count);
-    const uint32_t n_lights = (uint32_t)A.n_lights;
+    level_range(S.ws.ctrl + kCtrlNodeCount, S.n_level0, S.level, S.ws.node_cap, base, count);
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        NodeRes *nd = S.ws.nodes + base + i;
-        const float4 *q = reinterpret_cast<const float4 *>(nd);
-        const float4 a = q[0], b = q[1];
-        const uint32_t kind = __float_as_uint(a.w), first = __float_as_uint(b.x), aux = __float_as_uint(b.y),
-                       nchild = __float_as_uint(b.z), pix = __float_as_uint(b.w);
-        V3 v = mk(a.x, a.y, a.z);
-        if (kind == NODE_PASS) {                                               // render.hpp:249 / :275
-            const NodeRes *c = S.ws.nodes + first;
-            v = mk(c->value[0], c->value[1], c->value[2]);
-        } else if (kind == NODE_REFR) {                                        // :301
-            const NodeRes *c0 = S.ws.nodes + first, *c1 = c0 + 1;
-            const float fresnel = __uint_as_float(aux);
-            const V3 refr = mk(c0->value[0], c0->value[1], c0->value[2]), refl = mk(c1->value[0], c1->value[1], c1->value[2]);
-            v = (fresnel * refl) + ((1.0f - fresnel) * refr);
-        } else if (kind == NODE_TEX) {                                         // :211-238
-            V3 acc = mk(0.f, 0.f, 0.f);
-            for (uint32_t k = 0; k < n_lights; ++k) {
-                const float2 cv = S.ws.contrib[(size_t)aux * n_lights + k];
-                if (cv.y != 0.0f) acc = acc + (cv.x * v);                      // v still holds the sampled texture colour
-            }
-            v = acc;
-        } else if (kind == NODE_DIFF) {                                        // :151-208
-            const HitRec *h = S.ws.hits + aux;
-            const DevMaterial *m = A.materials + h->mat;
-            const V3 albedo = mk(m->albedo[0], m->albedo[1], m->albedo[2]);
-            V3 acc = mk(0.f, 0.f, 0.f);
-            for (uint32_t g = 0; g < nchild; ++g) {                            // a GI ray that missed is worth 0: adding it changes nothing
-                const NodeRes *c = S.ws.nodes + first + g;
-                acc = acc + mk(c->value[0], c->value[1], c->value[2]);
-            }
-            for (uint32_t k = 0; k < n_lights; ++k) {
-                const float2 cv = S.ws.contrib[(size_t)aux * n_lights + k];
-                if (cv.y != 0.0f) acc = acc + (cv.x * albedo);
-            }
-            const float div = (float)(A.diffuse_rays + 1);
-            v = mk(acc.x / div, acc.y / div, acc.z / div);
+    if (S.level != 0u) {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+            uint32_t pix;
+            (void)combine_node(S, S.ws.nodes + base + i, pix);
         }
-        if (kind != NODE_LEAF) { nd->value[0] = v.x; nd->value[1] = v.y; nd->value[2] = v.z; }
-        if (S.level == 0u && pix != 0xFFFFFFFFu) emit_pixel(S, pix, v);
+        return;
+    }
+    // depth 0: one thread per pixel slot; the camera rays of the batch's samples are nodes i, n_root + i, 2 n_root + i, ...
+    // final_color += colour, sample after sample; after the last sample pixels[y][x] = final_color / spp (render.hpp:66-74).
+    // The running sum of a pixel lives in ws.sumbuf between the batches of one pass and in the output buffer between the passes
+    // of a progressive frame (rtk_render_params.sample_begin); it is added to in sample order either way.
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < S.n_root; i += stride) {
+        V3 sum = mk(0.f, 0.f, 0.f);
+        uint32_t pix = 0xFFFFFFFFu;
+        for (uint32_t b = 0; b < S.n_batch; ++b) {
+            uint32_t p;
+            const V3 ret = combine_node(S, S.ws.nodes + (size_t)b * S.n_root + i, p);
+            if (b == 0u) {
+                pix = p;
+                if (pix == 0xFFFFFFFFu) break;                             // not a pixel of the frame (block overhanging its edge)
+                if (S.sample == 0) sum = mk(0.0f + ret.x, 0.0f + ret.y, 0.0f + ret.z);
+                else {
+                    const float *sb = (S.sample == S.r.sample_begin ? S.r.out : S.ws.sumbuf) + (size_t)pix * 3;
+                    sum = mk(sb[0] + ret.x, sb[1] + ret.y, sb[2] + ret.z);
+                }
+            } else {
+                sum = sum + ret;
+            }
+        }
+        if (pix == 0xFFFFFFFFu) continue;
+        if (S.sample + (int)S.n_batch == S.r.sample_end) {
+            float *o = S.r.out + (size_t)pix * 3;
+            if (S.r.sample_end == S.r.spp) {
+                const float n = (float)S.r.spp;
+                o[0] = sum.x / n; o[1] = sum.y / n; o[2] = sum.z / n;
+            } else {
+                o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+            }
+        } else {
+            float *sb = S.ws.sumbuf + (size_t)pix * 3;
+            sb[0] = sum.x; sb[1] = sum.y; sb[2] = sum.z;
+        }
     }
 }
 
@@ -661,7 +684,7 @@ void launch_shadow(const dev::StreamArgs &S, bool stats, unsigned units, hipStre
 
 }  // namespace
 
-// One sample of one frame.  Depth levels below `deep_level` use the workgroup-cooperative wave walk (coherent rays);
+// One batch of samples (S.sample .. S.sample + S.n_batch - 1) of one frame.  Depth levels below `deep_level` use the workgroup-cooperative wave walk (coherent rays);
 // from `deep_level` on `deep_mode` (RTK_TRACE_AUTO / _LANE / _WAVE) applies.  From depth `sort_from_level` on, the
 // level's rays and shading points are counting-sorted for coherence before they are cut into 64-ray work units.
 hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, int sort_from_level,
@@ -687,7 +710,7 @@ hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int dee
         S.hits_sorted = (level >= sort_from_level && level < A.max_depth) ? 1u : 0u;
         S.bin_children = (level + 1 >= sort_from_level && level < A.max_depth) ? 1u : 0u;
         S.bin_hits = S.hits_sorted;
-        if (level == 0) launch_path<true, 4, RTK_TRACE_WAVE>(S, stats, S.n_root / 64u, s);
+        if (level == 0) launch_path<true, 4, RTK_TRACE_WAVE>(S, stats, S.n_level0 / 64u, s);
         else if (!deep) launch_path<false, 4, RTK_TRACE_WAVE>(S, stats, group_units, s);
         else if (deep_mode == RTK_TRACE_LANE) launch_path<false, 1, RTK_TRACE_LANE>(S, stats, wave_units, s);
         else launch_path<false, 1, RTK_TRACE_AUTO>(S, stats, wave_units, s);

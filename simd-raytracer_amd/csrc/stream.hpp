@@ -72,10 +72,12 @@ struct StreamWs {
     uint32_t *hit_order;    // [hit_cap] hit ids of the current level in sorted order
 };
 
-// Samples of a frame are independent ray trees: up to kStreamLanes of them are in flight at once, each on its own HIP stream
-// with its own queues, so that the tail of one sample's level (a few slow work units) overlaps the other samples' work.
-// Only the last kernel of a sample (k_combine at depth 0, which adds the sample to the running pixel sums) is ordered
-// behind the previous sample's, by an event: the sums stay in sample order.
+// Samples of a frame are independent ray trees.  A BATCH of consecutive samples is traced together, level by level, through one
+// set of queues (one k_path / k_shadow / k_combine launch per level for the whole batch: fewer launches and level tails, and
+// the coherence sort has several samples' rays to make its 64-ray units from); the depth-0 k_combine adds a pixel's samples
+// in sample order.  Up to kStreamLanes batches are in flight at once, each on its own HIP stream with its own queues, so that
+// the tail of one batch's level overlaps the other batches' work; only the depth-0 k_combine of a batch is ordered behind the
+// previous batch's, by an event: the running pixel sums stay in sample order.  HBM is what pays: ~120 B per ray-tree node.
 constexpr int kStreamLanes = 8;          // upper bound; the default is 4 (api.hip rtk_knobs)
 
 struct StreamArgs {
@@ -84,8 +86,10 @@ struct StreamArgs {
     const uint32_t *lane_overflow[kStreamLanes];   // the overflow words of all lanes in use (k_combine at depth 0 emits nothing if any is set)
     uint32_t n_lanes;
     uint32_t level;
-    int sample;
-    uint32_t n_root;        // level-0 nodes: 64 per 8x8 pixel block of this rank
+    int sample;             // first sample of this launch's batch
+    uint32_t n_batch;       // samples traced together: the ray trees of samples [sample, sample + n_batch) share the queues
+    uint32_t n_root;        // level-0 nodes of ONE sample: 64 per 8x8 pixel block of this rank
+    uint32_t n_level0;      // = n_root * n_batch: sample b's camera ray of pixel slot i is node b * n_root + i
     uint32_t auto_min_lanes; // RTK_TRACE_AUTO: leave the wave-cooperative walk when fewer rays than this share a node
     uint32_t nodes_sorted;   // k_path: this level's nodes are taken through ws.node_order
     uint32_t hits_sorted;    // k_shadow: this level's shading points are taken through ws.hit_order

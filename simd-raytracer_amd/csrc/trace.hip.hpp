@@ -58,6 +58,7 @@ struct TreeView {
     const uint32_t *tri_ids;
     const DevShade *shade;
     const DevNode *leaves;       // the leaves of `nodes` alone, in traversal order (a = first leaf ref, b = count)
+    const DevNode *leaves_fast;  // RTK_TRAVERSAL_FAST: [8][n_leaves] the leaves front to back per direction octant; null = reference order
     uint32_t n_leaves;
     uint32_t n_nodes;
     float eps;
@@ -1043,13 +1044,25 @@ __device__ __forceinline__ void trace_list(const TreeView &T, const Ray &r, cons
                                            const V3 apex) {
     const uint32_t lane = __lane_id();
     bool live = active;                                                    // lanes still looking for their closest hit
+    // RTK_TRAVERSAL_FAST (rtk.h): the leaf list of the octant most of the wave's rays travel in, front to back.  Any order visits
+    // a superset of what each ray needs for its closest t (a leaf is skipped only when a nearer hit is already known); only
+    // which of several triangles at exactly that t wins depends on the order.
+    const DevNode *leaf_list = T.leaves;
+    if (T.leaves_fast != nullptr) {
+        const uint32_t half = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active));
+        uint32_t oct = 0u;
+        if (2u * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active & (r.d.x < 0.0f))) > half) oct |= 1u;
+        if (2u * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active & (r.d.y < 0.0f))) > half) oct |= 2u;
+        if (2u * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active & (r.d.z < 0.0f))) > half) oct |= 4u;
+        leaf_list = T.leaves_fast + (size_t)oct * T.n_leaves;
+    }
     uint32_t bundled = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(active));   // live lanes when the bundles were last made
     for (uint32_t base = 0; base < T.n_leaves; base += 64u) {
 #ifdef RTK_DEBUG_PHASES
         const unsigned long long pl0 = __builtin_readcyclecounter();
 #endif
         const bool have = base + lane < T.n_leaves;
-        const float4 *lp = reinterpret_cast<const float4 *>(T.leaves + (have ? base + lane : 0u));
+        const float4 *lp = reinterpret_cast<const float4 *>(leaf_list + (have ? base + lane : 0u));
         const float4 q0 = lp[0], q1 = lp[1];
         bool cand = false;
 #pragma unroll

@@ -19,14 +19,15 @@ int main(int argc, char **argv) {
     if (argc < 2) {
         std::puts("Usage: ./rtk_render FILE [--width W] [--height H] [--spp N] [--depth D] [--diffuse K] [--seed S] [--fov DEG]\n"
                   "                         [--trace auto|lane|wave] [--no-normalize] [--frames N] [--out image.ppm]\n"
-                  "                         [--world N]   one process per GPU, buckets dealt round-robin, RCCL all-gather of the frame");
+                  "                         [--world N]   one process per GPU, buckets dealt round-robin, RCCL all-gather of the frame\n"
+                  "                         [--fast-traversal]   front-to-back leaf order (same distances, ties may pick another triangle: not the parity mode)");
         return 1;
     }
     rtk_render_params p{};
     p.spp = 1; p.max_ray_depth = 5; p.diffuse_rays = 0; p.seed = 42; p.fov_degrees = 90.0;
     p.shadow_bias = p.reflection_bias = p.refraction_bias = 1e-4f;
     p.trace_mode = RTK_TRACE_AUTO; p.world_size = 1;
-    rtk_accel_params ap{8, 64, 1e-6f, 1, -1};
+    rtk_accel_params ap{8, 64, 1e-6f, 1, -1, RTK_TRAVERSAL_REFERENCE};
     std::string out = "image.ppm";
     int frames = 1, world = 0;
     for (int i = 2; i < argc; ++i) {
@@ -42,6 +43,7 @@ int main(int argc, char **argv) {
         else if (a == "--diffuse") p.diffuse_rays = std::atoi(val("--diffuse"));
         else if (a == "--seed") p.seed = static_cast<uint32_t>(std::strtoul(val("--seed"), nullptr, 10));
         else if (a == "--frames") frames = std::atoi(val("--frames"));
+        else if (a == "--fast-traversal") ap.traversal = RTK_TRAVERSAL_FAST;      // front-to-back leaf order: NOT the parity mode (rtk.h)
         else if (a == "--world") world = std::atoi(val("--world"));
         else if (a == "--fov") p.fov_degrees = std::atof(val("--fov"));
         else if (a == "--out") out = val("--out");

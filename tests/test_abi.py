@@ -28,7 +28,7 @@ def test_abi_version_and_struct_sizes(rtk):
     assert rtk.RAY_DTYPE.itemsize == 24
     assert rtk.HIT_DTYPE.itemsize == 32
     assert ctypes.sizeof(rtk.Counters) == 64
-    assert ctypes.sizeof(rtk.AccelParams) == 20
+    assert ctypes.sizeof(rtk.AccelParams) == 24          # + traversal (ABI 4)
     assert ctypes.sizeof(rtk.RenderParams) == 72        # 64 + sample_begin, sample_count (ABI 3)
     assert ctypes.sizeof(rtk.SceneInfo) == 44 and ctypes.sizeof(rtk.SceneDesc) == 264
 

@@ -10,6 +10,8 @@ CASES = {
     "cfg3 scene8 1080p spp1 d10": (f"{S}/hw11/scene8.crtscene", dict(width=1920, height=1080, spp=1, max_ray_depth=10)),
     "cfg3 scene8 1080p spp4 d10": (f"{S}/hw11/scene8.crtscene", dict(width=1920, height=1080, spp=4, max_ray_depth=10)),
     "cfg4 hw15s2 960 spp8 d5 gi1": (f"{S}/hw15/scene2.crtscene", dict(width=960, height=960, spp=8, max_ray_depth=5, diffuse_rays=1)),
+    "cfg4f hw15s2 1920 spp16 d5 gi1": (f"{S}/hw15/scene2.crtscene", dict(width=1920, height=1920, spp=16, max_ray_depth=5, diffuse_rays=1)),
+    "cfg5f hw15s2 4K spp8 d10 gi1": (f"{S}/hw15/scene2.crtscene", dict(width=3840, height=2160, spp=8, max_ray_depth=10, diffuse_rays=1)),
     "cfg5 hw15s2 4K spp4 d10 gi1": (f"{S}/hw15/scene2.crtscene", dict(width=3840, height=2160, spp=4, max_ray_depth=10, diffuse_rays=1)),
     "hw15s2 1920 spp1 d5": (f"{S}/hw15/scene2.crtscene", dict(width=1920, height=1920, spp=1, max_ray_depth=5)),
 }
@@ -26,9 +28,9 @@ for cname, (path, kw) in CASES.items():
             acc.render_frame_device(cfg, out.data_ptr(), st)
         except rtk.RtkError as e:
             print(f"{cname:32s} {names[mode]:8s} n/a ({e.code})"); continue
-        for _ in range(7): acc.render_frame_device(cfg, out.data_ptr(), st)   # cost feedback / engine trials settle on the first frames
+        for _ in range(int(os.environ.get("TC_WARM", "7"))): acc.render_frame_device(cfg, out.data_ptr(), st)   # cost feedback / engine trials settle on the first frames
         torch.cuda.synchronize()
-        n = 8
+        n = int(os.environ.get("TC_REPS", "8"))
         t0 = time.perf_counter()
         for _ in range(n): acc.render_frame_device(cfg, out.data_ptr(), st)
         torch.cuda.synchronize()
