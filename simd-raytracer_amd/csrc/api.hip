@@ -68,7 +68,8 @@ struct rtk_knobs {
     bool stream_debug = false;                              // RTK_STREAM_DEBUG
     bool stream_side = true;                                // RTK_STREAM_SIDE: k_shadow on side streams
     int stream_lanes = 4;                                   // RTK_STREAM_LANES: batches of a frame in flight at once (1..kStreamLanes); 8 measured no faster
-    int stream_batch = 1;                                   // RTK_STREAM_BATCH: samples traced together per launch (stream.hpp)
+    int stream_slices = 0;                                  // RTK_STREAM_SLICES: waves per work unit of the streaming levels (1, 2, 4; 0 = by the tree's leaf sizes)
+    int stream_batch = 0;                                   // RTK_STREAM_BATCH: samples traced together per launch (stream.hpp; 0 = the pass split evenly over the lanes)
     int stream_mem_gb = 96;                                 // RTK_STREAM_MEM_GB: budget for the queues of all batches in flight
     int stream_side_below = 2;                              // RTK_STREAM_SIDE_BELOW: k_shadow on side streams while at most this many samples are in flight
     bool traversal_fast = false;                            // RTK_TRAVERSAL_FAST: front-to-back leaf order (rtk.h; NOT the parity mode)
@@ -98,7 +99,8 @@ struct rtk_knobs {
         if (geti("RTK_STREAM_DEBUG", v)) k.stream_debug = v != 0;
         if (geti("RTK_STREAM_SIDE", v)) k.stream_side = v != 0;
         if (geti("RTK_TRAVERSAL_FAST", v)) k.traversal_fast = v != 0;
-        if (geti("RTK_STREAM_BATCH", v) && v >= 1 && v <= 4096) k.stream_batch = int(v);
+        if (geti("RTK_STREAM_SLICES", v) && (v == 0 || v == 1 || v == 2 || v == 4)) k.stream_slices = int(v);
+        if (geti("RTK_STREAM_BATCH", v) && v >= 0 && v <= 4096) k.stream_batch = int(v);
         if (geti("RTK_STREAM_MEM_GB", v) && v >= 1 && v <= 256) k.stream_mem_gb = int(v);
         if (geti("RTK_STREAM_SIDE_BELOW", v) && v >= 0) k.stream_side_below = int(v);
         if (geti("RTK_STREAM_LANES", v) && v >= 1 && v <= rtk::dev::kStreamLanes) k.stream_lanes = int(v);
@@ -120,6 +122,10 @@ struct rtk_accel {
     rtk::DevNode *d_leaves = nullptr;
     rtk::DevNode *d_leaves_fast = nullptr;    // RTK_TRAVERSAL_FAST: 8 front-to-back orders of the leaves (null in the parity mode)
     bool fast_traversal = false;
+    // Streaming pipeline: waves per 64-ray work unit.  Helper waves pay where a ray meets large leaves (hw11/scene8, a
+    // triangle reference sits in a leaf of 258 on average: 23.3 ms with three helpers, 36.6 without) and cost where it does not
+    // (hw15/scene2, 109: 64.1 ms with, 47.8 without -- the helpers' wave slots are worth more as owners of further units).
+    int stream_slices_auto = 4;
     rtk::DevTri *d_tris = nullptr;
     uint32_t *d_tri_ids = nullptr;
     rtk::DevShade *d_shade = nullptr;
@@ -511,6 +517,11 @@ int rtk_accel_build(const rtk_scene *scene, const rtk_accel_params *params, rtk_
         }
         for (const DevMaterial &m : a->scene.materials) if (m.kind == RTK_MAT_REFRACTIVE) a->has_refractive = true;
         a->knobs = rtk_knobs::from_env();
+        {
+            double refs = 0.0, sq = 0.0;                        // size of the leaf a random triangle reference lives in
+            for (const DevNode &l : a->tree.dev_leaves) { refs += double(l.b); sq += double(l.b) * double(l.b); }
+            a->stream_slices_auto = (refs > 0.0 && sq / refs < 150.0) ? 1 : 4;
+        }
         a->fast_traversal = a->params.traversal == RTK_TRAVERSAL_FAST || a->knobs.traversal_fast;
         if (a->fast_traversal) build_fast_leaf_orders(a->tree);
         a->coords_small = true;
@@ -819,7 +830,12 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         const size_t nodes_per_sample = n_root * factor + 4096;
         const size_t bytes_per_node = sizeof(dev::RayRec) + sizeof(dev::NodeRes) + sizeof(uint32_t) +
                                       (sizeof(dev::HitRec) + sizeof(uint32_t) + sizeof(float2) * (a->scene.lights.empty() ? 1 : a->scene.lights.size())) / 2 + 1;
-        int batch = n_pass < a->knobs.stream_batch ? n_pass : a->knobs.stream_batch;
+        // Measured (gpurun_out/r03d-f, hw15/scene2 and hw11/scene8 at the BASELINE sizes): four batches in flight, each a
+        // quarter of the pass, beat both more, smaller launches and fewer, larger ones (1920x1920, 16 samples, no helpers:
+        // 53.1 ms one sample per launch, 47.6 four, 61.6 eight in two lanes; 960x960, 8 samples: 14.4 -> 9.5 ms).
+        const int even = (n_pass + a->knobs.stream_lanes - 1) / a->knobs.stream_lanes;
+        const int want = a->knobs.stream_batch > 0 ? a->knobs.stream_batch : even;
+        int batch = n_pass < want ? n_pass : want;
         const size_t budget = size_t(a->knobs.stream_mem_gb) << 30;
         while (batch > 1 && (nodes_per_sample * size_t(batch) > 0xF0000000ull || nodes_per_sample * size_t(batch) * bytes_per_node > budget)) batch -= 1;
         const int n_launch = (n_pass + batch - 1) / batch;
@@ -864,7 +880,8 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             const hipError_t es = launch_stream_sample(S, p->collect_stats != 0, deep_level, deep_mode, sort_from, ls, wait, done,
                                                        // (side streams help while few rays are in flight: spp 1 16.7 -> 9.1 ms on config 3;
                                                        // with four lanes the GPU is full already and they cost 20 %)
-                                                       (a->knobs.stream_side && lanes <= 2 && batch * lanes <= a->knobs.stream_side_below) ? &a->lane_side[j] : nullptr);
+                                                       (a->knobs.stream_side && lanes <= 2 && batch * lanes <= a->knobs.stream_side_below) ? &a->lane_side[j] : nullptr,
+                                                       a->knobs.stream_slices > 0 ? a->knobs.stream_slices : a->stream_slices_auto);
             if (es != hipSuccess) return hip_fail(es, "launch streaming pipeline");
         }
         // join: the caller's stream continues behind the last sample of every lane

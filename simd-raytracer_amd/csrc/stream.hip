@@ -211,7 +211,10 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
     for (uint32_t j = 0; j < level; ++j) hit_base += ctrl[kCtrlHitCount + j];
     const uint32_t n_items = (count + 63u) >> 6;
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u, SLICES > 1 ? group_sh->bundles : nullptr};
+    // bundles of the current trace (trace.hip.hpp "Bundle culling"): the group's shared block, or one area per wave when every wave owns rays
+    __shared__ __attribute__((aligned(16))) float wave_bundles[SLICES > 1 ? 1 : 4][kMaxBundles * kBundleFloats];
+    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u,
+                   SLICES > 1 ? group_sh->bundles : (MODE == RTK_TRACE_WAVE ? wave_bundles[(threadIdx.x >> 6) & 3u] : nullptr)};
     sx.rebundle = false;
     uint32_t nrays = 0;
 
@@ -405,7 +408,10 @@ __global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
     const uint32_t n_items = ((n_hits + 63u) >> 6) * n_lights;
     const float PI_F = 3.14159265358979323846f;
     Stats st = {0, 0, 0, 0, 0, 0};
-    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u, SLICES > 1 ? group_sh->bundles : nullptr};
+    // bundles of the current trace (trace.hip.hpp "Bundle culling"): the group's shared block, or one area per wave when every wave owns rays
+    __shared__ __attribute__((aligned(16))) float wave_bundles[SLICES > 1 ? 1 : 4][kMaxBundles * kBundleFloats];
+    SliceCtx sx = {SLICES > 1 ? group_sh : nullptr, A.slice_min_tris, 0u, true, 0u,
+                   SLICES > 1 ? group_sh->bundles : (MODE == RTK_TRACE_WAVE ? wave_bundles[(threadIdx.x >> 6) & 3u] : nullptr)};
     sx.rebundle = false;
     uint32_t nrays = 0;
 
@@ -688,7 +694,7 @@ void launch_shadow(const dev::StreamArgs &S, bool stats, unsigned units, hipStre
 // from `deep_level` on `deep_mode` (RTK_TRACE_AUTO / _LANE / _WAVE) applies.  From depth `sort_from_level` on, the
 // level's rays and shading points are counting-sorted for coherence before they are cut into 64-ray work units.
 hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, int sort_from_level,
-                                hipStream_t s, hipEvent_t wait_before_emit, hipEvent_t done, const StreamSide *side) {
+                                hipStream_t s, hipEvent_t wait_before_emit, hipEvent_t done, const StreamSide *side, int slices) {
     dev::StreamArgs S = base;
     const dev::RenderArgs &A = S.r;
     if (S.n_root == 0) return hipSuccess;
@@ -710,7 +716,10 @@ hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int dee
         S.hits_sorted = (level >= sort_from_level && level < A.max_depth) ? 1u : 0u;
         S.bin_children = (level + 1 >= sort_from_level && level < A.max_depth) ? 1u : 0u;
         S.bin_hits = S.hits_sorted;
-        if (level == 0) launch_path<true, 4, RTK_TRACE_WAVE>(S, stats, S.n_level0 / 64u, s);
+        if (level == 0 && slices == 1) launch_path<true, 1, RTK_TRACE_WAVE>(S, stats, S.n_level0 / 64u, s);
+        else if (level == 0) launch_path<true, 4, RTK_TRACE_WAVE>(S, stats, S.n_level0 / 64u, s);
+        else if (!deep && slices == 2) launch_path<false, 2, RTK_TRACE_WAVE>(S, stats, group_units * 2u, s);
+        else if (!deep && slices == 1) launch_path<false, 1, RTK_TRACE_WAVE>(S, stats, wave_units, s);
         else if (!deep) launch_path<false, 4, RTK_TRACE_WAVE>(S, stats, group_units, s);
         else if (deep_mode == RTK_TRACE_LANE) launch_path<false, 1, RTK_TRACE_LANE>(S, stats, wave_units, s);
         else launch_path<false, 1, RTK_TRACE_AUTO>(S, stats, wave_units, s);
@@ -731,7 +740,9 @@ hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int dee
                 if (e == hipSuccess) e = hipStreamWaitEvent(ss, side->ready[par], 0);
                 if (e != hipSuccess) return e;
             }
-            if (!deep) launch_shadow<4, RTK_TRACE_WAVE>(S, stats, group_units, ss);
+            if (!deep && slices == 2) launch_shadow<2, RTK_TRACE_WAVE>(S, stats, group_units * 2u, ss);
+            else if (!deep && slices == 1) launch_shadow<1, RTK_TRACE_WAVE>(S, stats, wave_units, ss);
+            else if (!deep) launch_shadow<4, RTK_TRACE_WAVE>(S, stats, group_units, ss);
             else if (deep_mode == RTK_TRACE_LANE) launch_shadow<1, RTK_TRACE_LANE>(S, stats, wave_units, ss);
             else launch_shadow<1, RTK_TRACE_AUTO>(S, stats, wave_units, ss);
         }

@@ -109,8 +109,9 @@ struct StreamSide {
 };
 // `wait_before_emit` (may be null): the depth-0 k_combine waits for it (the previous sample's `done`); `done` (may be null) is
 // recorded behind it.  `side` (may be null): run the k_shadow kernels there.
+// `slices`: waves per 64-ray work unit of the queue-driven levels (4: an owner and three helpers that share its large leaves; 2; 1: no helpers)
 hipError_t launch_stream_sample(const dev::StreamArgs &base, bool stats, int deep_level, int deep_mode, int sort_from_level,
-                                hipStream_t s, hipEvent_t wait_before_emit, hipEvent_t done, const StreamSide *side);
+                                hipStream_t s, hipEvent_t wait_before_emit, hipEvent_t done, const StreamSide *side, int slices = 4);
 // ORs the lanes' overflow words into lane 0's, then zeroes the ray counters if it is set (the megakernel that redoes the frame counts from scratch)
 hipError_t launch_stream_overflow_reset(const dev::StreamArgs &S, hipStream_t s);
 
