@@ -327,7 +327,10 @@ def main() -> None:
     first_frame_ms = None
     if world == 1:
         cold = rtk.KdTreeSimdAccel(rtk.parse_scene_file(SCENE), device=local_rank)
-        cold.render_frame_device(rtk.RenderConfig(width=64, height=64), frame.data_ptr(), stream.cuda_stream)     # context, uploads, code load
+        # context, uploads, code load: a small frame through the kernel the timed frame will use (a 64x64 frame would pick the
+        # 8-wave kernel by itself, and the first launch of a kernel pays for loading its code)
+        cold.render_frame_device(rtk.RenderConfig(width=64, height=64, trace_mode=3 if args.trace_mode == 0 else args.trace_mode),
+                                 frame.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize()
         first_frame_ms = event_ms(torch, stream, lambda: cold.render_frame_device(cfg, frame.data_ptr(), stream.cuda_stream), 1)
         del cold

@@ -72,6 +72,7 @@ struct rtk_knobs {
     int stream_batch = 0;                                   // RTK_STREAM_BATCH: samples traced together per launch (stream.hpp; 0 = the pass split evenly over the lanes)
     int stream_mem_gb = 96;                                 // RTK_STREAM_MEM_GB: budget for the queues of all batches in flight
     int stream_side_below = 2;                              // RTK_STREAM_SIDE_BELOW: k_shadow on side streams while at most this many samples are in flight
+    bool first_frame_prior = true;                          // RTK_FIRST_FRAME_PRIOR: launch order of a shape's first frame from k_block_prior
     bool traversal_fast = false;                            // RTK_TRAVERSAL_FAST: front-to-back leaf order (rtk.h; NOT the parity mode)
 
     static rtk_knobs from_env() {
@@ -99,6 +100,7 @@ struct rtk_knobs {
         if (geti("RTK_STREAM_DEBUG", v)) k.stream_debug = v != 0;
         if (geti("RTK_STREAM_SIDE", v)) k.stream_side = v != 0;
         if (geti("RTK_TRAVERSAL_FAST", v)) k.traversal_fast = v != 0;
+        if (geti("RTK_FIRST_FRAME_PRIOR", v)) k.first_frame_prior = v != 0;
         if (geti("RTK_STREAM_SLICES", v) && (v == 0 || v == 1 || v == 2 || v == 4)) k.stream_slices = int(v);
         if (geti("RTK_STREAM_BATCH", v) && v >= 0 && v <= 4096) k.stream_batch = int(v);
         if (geti("RTK_STREAM_MEM_GB", v) && v >= 1 && v <= 256) k.stream_mem_gb = int(v);
@@ -924,16 +926,35 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
                                      (uint64_t(uint32_t(g.rank)) << 32) | uint32_t(g.world),
                                      (uint64_t(uint32_t(p->spp)) << 32) | (uint64_t(uint32_t(p->max_ray_depth)) << 16) | uint32_t(p->diffuse_rays),
                                      (uint64_t(uint32_t(g.bucket)) << 32) | (uint64_t(uint32_t(g.sample_end - g.sample_begin) & 0xFFFFu) << 16) | uint32_t(p->trace_mode)};
-            if (a->fb_units != units) {
+            if (a->fb_units < units) {
+                // (capacity, never shrunk; the first allocation also covers the scene's own frame size, so that a small frame
+                // rendered first -- a warm-up -- does not leave three hipMallocs, ~0.1 ms, in front of the first full-size frame)
+                size_t cap = units;
+                {
+                    const uint32_t bk = g.bucket, bs = g.blocks_side;
+                    const uint64_t tx = (uint64_t(a->scene.width > 0 ? a->scene.width : 0) + bk - 1) / bk, ty = (uint64_t(a->scene.height > 0 ? a->scene.height : 0) + bk - 1) / bk;
+                    const uint64_t native = tx * ty * bs * bs;
+                    if (a->fb_units == 0 && native > cap && native <= (1ull << 24)) cap = size_t(native);
+                }
                 (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
                 a->fb_cost = a->fb_order = nullptr; a->fb_bins = nullptr; a->fb_units = 0; a->fb_valid = false; a->fb_order_valid = false;
-                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_cost), units * sizeof(uint32_t)));
-                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_order), (2 * units + 4) * sizeof(uint32_t)));   // order, header, workgroup list
-                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_bins), units));
-                a->fb_units = units;
+                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_cost), cap * sizeof(uint32_t)));
+                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_order), (2 * cap + 4 + 8) * sizeof(uint32_t)));   // order, header, workgroup list, prior's counters
+                RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->fb_bins), cap));
+                a->fb_units = cap;
             }
             const bool same_shape = a->fb_valid && std::memcmp(sig, a->fb_sig, sizeof(sig)) == 0;
             if (!same_shape) a->fb_order_valid = false;
+            // The first frame of a shape has no costs to go by: a prior from the camera rays alone stands in for them
+            // (k_block_prior: background blocks packed four to a workgroup, the others by what their centre ray looks at).
+            // A one-shot render is exactly this frame (the reference CLI renders one, src/main.cpp:13-25).
+            const bool prior = !same_shape && a->knobs.first_frame_prior && frame_mode == RTK_TRACE_GROUP4 && p->collect_stats == 0;
+            if (prior) {
+                const hipError_t ep = launch_block_prior(A, a->fb_bins, a->fb_order, a->fb_order + units + 4, a->fb_order + units,
+                                                         a->fb_order + 2 * units + 4, 4u, s);
+                if (ep != hipSuccess) return hip_fail(ep, "launch k_block_prior");
+                A.order_in = a->fb_order; A.order_hdr = a->fb_order + units; A.wg_list = a->fb_order + units + 4;
+            }
             if (same_shape) {
                 // The order is refreshed from the newest costs every few frames only: the sort is one small workgroup whose
                 // ~28 us sit in front of the frame, and an order that is a few frames old is as good (costs move slowly).

@@ -931,6 +931,91 @@ hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool fo
 #endif
 }
 
+// A prior for the FIRST frame of a shape, when no frame has reported its blocks' costs yet.  One thread per 8x8 pixel block
+// sorts it into one of three classes, and a second small kernel lays the launch list out class by class (no sort: ~10 us
+// in front of the frame where k_order_by_cost needs 66):
+//   1  some probe ray (the four corner pixels, the centre) enters the tree's root box -- first, a workgroup each
+//   0  none does: background -- packed four to a workgroup, last
+//   (2 is kept for a class to be started before both)
+// Only the launch order depends on the classes, no result.  From the second frame on the measured costs take over.
+namespace dev {
+__global__ __launch_bounds__(256) void k_block_prior(RenderArgs A, uint8_t *cls, uint32_t *count /* [3], zeroed */) {
+    const uint32_t unit = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool have = unit < A.n_units;
+    const uint32_t bpb = A.blocks_per_bucket_side * A.blocks_per_bucket_side;
+    const uint32_t local_bucket = (have ? unit : 0u) / bpb, sub = (have ? unit : 0u) % bpb;
+    const uint32_t bucket = rank_bucket((uint32_t)A.rank, local_bucket, (uint32_t)A.world, A.skew_q);
+    const uint32_t bx = (bucket % A.tiles_x) * A.bucket, by = (bucket / A.tiles_x) * A.bucket;
+    const uint32_t x0 = bx + (sub % A.blocks_per_bucket_side) * 8u, y0 = by + (sub / A.blocks_per_bucket_side) * 8u;
+    const bool in_frame = have && bucket < A.n_buckets && x0 < A.width && y0 < A.height;
+    const uint32_t x1 = x0 + 7u < A.width ? x0 + 7u : A.width - 1u, y1 = y0 + 7u < A.height ? y0 + 7u : A.height - 1u;
+    RenderArgs P = A;
+    P.spp = 1;                                                                  // pixel centres: this is an estimate
+    const float4 *root = reinterpret_cast<const float4 *>(A.tree.nodes);
+    const float4 r0 = root[0], r1 = root[1];
+    float t_min;
+    const Ray centre = camera_ray(P, in_frame ? (x0 + x1) >> 1 : 0u, in_frame ? (y0 + y1) >> 1 : 0u, 0u);
+    const bool centre_in = in_frame && slab(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, centre, t_min);
+    bool enters = centre_in;
+    if (in_frame) {
+        const uint32_t px[4] = {x0, x1, x0, x1}, py[4] = {y0, y0, y1, y1};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const Ray r = camera_ray(P, px[i], py[i], 0u);
+            enters = enters | slab(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r, t_min);
+        }
+    }
+    // (Knowing what the centre ray HITS -- a mirror whose reflections fan out over the mesh is where config 2's longest blocks
+    // are -- would give a better order still: the frame went from 0.37 to 0.29 ms with such blocks first.  But tracing the 32,400
+    // centre rays, 64 to a wave, takes 0.24 ms: their bundles are 64 pixels wide and cull nothing.  Measured, not kept.)
+    const uint32_t c = enters ? 1u : 0u;
+    if (have) cls[unit] = (uint8_t)c;
+#pragma unroll
+    for (uint32_t q = 0; q < 3u; ++q) {                                        // one atomic per wave and class
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(have && c == q);
+        if (m != 0ull && (int)__lane_id() == __builtin_ctzll(m)) atomicAdd(count + q, (uint32_t)__popcll(m));
+    }
+}
+
+// order[] = the blocks class by class (2, 1, 0), wg_list / hdr as k_order_by_cost leaves them (RenderArgs::wg_list)
+__global__ __launch_bounds__(256) void k_prior_layout(const uint8_t *cls, const uint32_t *count, uint32_t *cursor /* [3], zeroed */,
+                                                      uint32_t *order, uint32_t *wg_list, uint32_t *hdr, uint32_t n, uint32_t pack) {
+    const uint32_t unit = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool have = unit < n;
+    const uint32_t c = have ? (uint32_t)cls[unit] : 3u;
+    const uint32_t n2 = count[2], n1 = count[1], n0 = count[0];
+    uint32_t pos = 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < 3u; ++q) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(have && c == q);
+        if (m == 0ull) continue;
+        const int leader = __builtin_ctzll(m);
+        uint32_t first = 0u;
+        if ((int)__lane_id() == leader) first = atomicAdd(cursor + q, (uint32_t)__popcll(m));
+        first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+        if (c == q) pos = first + (uint32_t)__popcll(m & ((1ull << __lane_id()) - 1ull));
+    }
+    if (have) {
+        const uint32_t at = c == 2u ? pos : (c == 1u ? n2 + pos : n2 + n1 + pos);
+        order[at] = unit;
+        if (c != 0u) wg_list[at] = unit;
+        else if (pos % pack == 0u) wg_list[n2 + n1 + pos / pack] = 0x80000000u | at;
+    }
+    if (unit == 0u) { hdr[0] = n2 + n1 + (n0 + pack - 1u) / pack; hdr[1] = n; }
+}
+}  // namespace dev
+
+hipError_t launch_block_prior(const dev::RenderArgs &A, uint8_t *cls, uint32_t *order, uint32_t *wg_list, uint32_t *hdr,
+                              uint32_t *scratch /* [6] */, uint32_t pack, hipStream_t s) {
+    if (A.n_units == 0u) return hipSuccess;
+    hipError_t e = hipMemsetAsync(scratch, 0, 6 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (A.n_units + 255u) / 256u;
+    hipLaunchKernelGGL(dev::k_block_prior, dim3(blocks), dim3(256), 0, s, A, cls, scratch);
+    hipLaunchKernelGGL(dev::k_prior_layout, dim3(blocks), dim3(256), 0, s, cls, scratch, scratch + 3, order, wg_list, hdr, A.n_units, pack);
+    return hipGetLastError();
+}
+
 // Counting sort of the pixel blocks by last frame's cost, most expensive first.  One workgroup: a frame has tens of
 // thousands of blocks, the whole job is two passes over a few hundred KB.
 namespace dev {

@@ -122,6 +122,11 @@ hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool fo
 hipError_t launch_order_by_cost(const uint32_t *cost, uint8_t *bins /* [n] scratch */, uint32_t *order, uint32_t *wg_list /* [n] */,
                                 uint32_t *hdr /* [2] */, uint32_t n, uint32_t light_below, uint32_t floor_below, uint32_t pack,
                                 hipStream_t s);
+// first frame of a shape: the launch list (order, wg_list, hdr as launch_order_by_cost leaves them) from the camera rays alone:
+// blocks whose centre ray hits a reflective / refractive surface, then blocks that enter the tree, then background blocks `pack`
+// to a workgroup.  cls [n_units] and scratch [6] are work space.
+hipError_t launch_block_prior(const dev::RenderArgs &A, uint8_t *cls, uint32_t *order, uint32_t *wg_list, uint32_t *hdr,
+                              uint32_t *scratch, uint32_t pack, hipStream_t s);
 hipError_t launch_twopass(const dev::RenderArgs &A, bool stats, bool forks, hipStream_t s);
 hipError_t launch_assemble(const dev::AssembleArgs &A, hipStream_t s);
 hipError_t launch_camera_rays(const dev::RenderArgs &A, int sample, rtk_ray *d_rays, hipStream_t s);
