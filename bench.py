@@ -238,6 +238,40 @@ def synthetic_extras(rtk, torch, dist, stream, rank: int, world: int) -> dict:
             "n_gpus": world, **synth}
 
 
+def fast_traversal_extras(rtk, torch, stream, parity_frame) -> dict:
+    """RTK_TRAVERSAL_FAST (front-to-back leaf order, rtk.h) beside the parity mode: NOT the headline -- ties between triangles hit at
+    exactly the same distance may resolve differently, so a few pixels differ.  Config 2 and config 3, steady state."""
+    import numpy as np
+
+    out = {"what": "RTK_TRAVERSAL_FAST: leaves front to back per direction octant; same closest distance for every ray, ties may pick "
+                   "another triangle; off by default (include/rtk.h)"}
+    acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(SCENE), traversal=rtk.TRAVERSAL_FAST)
+    cfg = rtk.RenderConfig(width=WIDTH, height=HEIGHT, spp=SPP, max_ray_depth=DEPTH, diffuse_rays=DIFFUSE)
+    buf = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda")
+    for _ in range(20):
+        acc.render_frame_device(cfg, buf.data_ptr(), stream.cuda_stream)
+    ms = event_ms(torch, stream, lambda: acc.render_frame_device(cfg, buf.data_ptr(), stream.cuda_stream), 50)
+    rays = acc.last_counters()["rays"]
+    diff = (buf != parity_frame).any(dim=2)
+    q = lambda t: (255.999 * t.clamp(0, 1).double()).to(torch.uint8)
+    out["config2"] = {"ms": ms, "Mrays_s": rays / ms / 1e3, "rays": rays, "pixels_differing_from_parity_frame": int(diff.sum()),
+                      "pixels_differing_in_8_bit": int((q(buf) != q(parity_frame)).any(dim=2).sum()),
+                      "max_abs_diff": float((buf - parity_frame).abs().max())}
+    scene8 = os.path.join(SCENES, "hw11", "scene8.crtscene")
+    res = {}
+    for name, trav in (("parity", rtk.TRAVERSAL_REFERENCE), ("fast", rtk.TRAVERSAL_FAST)):
+        a = rtk.KdTreeSimdAccel(rtk.parse_scene_file(scene8), traversal=trav)
+        c = rtk.RenderConfig(width=1920, height=1080, spp=4, max_ray_depth=10)
+        b = torch.empty((1080, 1920, 3), dtype=torch.float32, device="cuda")
+        for _ in range(5):
+            a.render_frame_device(c, b.data_ptr(), stream.cuda_stream)
+        m = min(event_ms(torch, stream, lambda: a.render_frame_device(c, b.data_ptr(), stream.cuda_stream), 1) for _ in range(3))
+        res[name] = (m, a.last_counters()["rays"], b)
+    out["config3"] = {"ms": res["fast"][0], "Mrays_s": res["fast"][1] / res["fast"][0] / 1e3, "parity_ms": res["parity"][0],
+                      "pixels_differing_in_8_bit": int((q(res["fast"][2]) != q(res["parity"][2])).any(dim=2).sum())}
+    return out
+
+
 def frame_extras(rtk, torch, stream) -> dict:
     """BASELINE configs 3, 4 and 5 at their real frame sizes (N = 1; RTK_TRACE_AUTO picks the engine on the first frames)."""
     frames = {}
@@ -450,6 +484,7 @@ def main() -> None:
         extras_out = {"synthetic_2p24": synthetic_extras(rtk, torch, dist, stream, rank, world)}      # every rank takes part
         if world == 1:
             extras_out["frames"] = frame_extras(rtk, torch, stream)
+            extras_out["fast_traversal"] = fast_traversal_extras(rtk, torch, stream, frame)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # the dominant kernel is k_render; one launch processes this rank's share of the frame

@@ -162,6 +162,10 @@ struct rtk_accel {
     hipEvent_t trial_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t trial_sig[3] = {0, 0, 0};
     int trial_state = 0;
+    // number of workgroups in fb_order's workgroup list, read back behind the sort that made it (pinned host word + event)
+    uint32_t *fb_nwgs_host = nullptr;
+    hipEvent_t fb_nwgs_ev = nullptr;
+    bool fb_nwgs_pending = false, fb_nwgs_known = false;
     bool fb_valid = false;           // fb_cost holds the costs of a frame of shape fb_sig
     bool fb_order_valid = false;     // fb_order was made from such costs
     // ray repacking workspace (batched intersect, repack.hip)
@@ -590,6 +594,8 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
         for (auto &e : a->trial_ev) if (e) (void)hipEventDestroy(e);
         if (a->rp_done) (void)hipEventDestroy(a->rp_done);
+        if (a->fb_nwgs_ev) (void)hipEventDestroy(a->fb_nwgs_ev);
+        if (a->fb_nwgs_host) (void)hipHostFree(a->fb_nwgs_host);
     }
     delete a;
 }
@@ -969,6 +975,15 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
                     if (eo != hipSuccess) return hip_fail(eo, "launch k_order_by_cost");
                     a->fb_order_valid = true;
                     a->fb_age = 0;
+                    // how many workgroups the list has: known on the host a frame or two later; until then the launch covers every block
+                    if (!a->fb_nwgs_host) {
+                        RTK_HIP(hipHostMalloc(reinterpret_cast<void **>(&a->fb_nwgs_host), sizeof(uint32_t), hipHostMallocDefault));
+                        RTK_HIP(hipEventCreateWithFlags(&a->fb_nwgs_ev, hipEventDisableTiming));
+                    }
+                    a->fb_nwgs_known = false;
+                    RTK_HIP(hipMemcpyAsync(a->fb_nwgs_host, a->fb_order + units, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    RTK_HIP(hipEventRecord(a->fb_nwgs_ev, s));
+                    a->fb_nwgs_pending = true;
                 }
                 a->fb_age += 1;
                 A.order_in = a->fb_order; A.order_hdr = a->fb_order + units; A.wg_list = a->fb_order + units + 4;
@@ -977,7 +992,13 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             std::memcpy(a->fb_sig, sig, sizeof(sig));
             a->fb_valid = true;
         }
-        const hipError_t e = launch_render(A, frame_mode, p->collect_stats != 0, general, s);
+        unsigned n_wgs = 0;
+        if (A.wg_list != nullptr && A.order_in == a->fb_order && a->fb_order_valid) {
+            if (a->fb_nwgs_pending && hipEventQuery(a->fb_nwgs_ev) == hipSuccess) { a->fb_nwgs_pending = false; a->fb_nwgs_known = true; }
+            else if (a->fb_nwgs_pending) (void)hipGetLastError();            // not ready: clear the sticky status
+            if (a->fb_nwgs_known && !a->fb_nwgs_pending) n_wgs = *a->fb_nwgs_host;
+        }
+        const hipError_t e = launch_render(A, frame_mode, p->collect_stats != 0, general, s, n_wgs);
         if (e != hipSuccess) return hip_fail(e, "launch k_render");
     }
     if (trial_end) RTK_HIP(hipEventRecord(trial_end, s));

@@ -908,7 +908,7 @@ hipError_t launch_intersect(const dev::IntersectArgs &A, int mode, bool stats, h
     }
 }
 
-hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool forks, hipStream_t s) {
+hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool forks, hipStream_t s, unsigned n_workgroups) {
 #ifdef RTK_ONLY_LEAN_G4     // `make asm-lean`: the benchmark's kernel alone, for quick looks at its ISA (not a product build)
     hipLaunchKernelGGL((dev::k_render<RTK_TRACE_WAVE, false, false, false, 4>), dim3(A.n_units), dim3(256), 0, s, A);
     return hipGetLastError();
@@ -923,7 +923,10 @@ hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool fo
     switch (mode) {
         case RTK_TRACE_LANE: return launch_render_mode<RTK_TRACE_LANE, 1>(A, packed, stats, forks, lds, lds_bytes, s);
         case RTK_TRACE_WAVE: return launch_render_mode<RTK_TRACE_WAVE, 1>(A, packed, stats, forks, lds, lds_bytes, s);
-        case RTK_TRACE_GROUP4: return launch_render_mode<RTK_TRACE_WAVE, 4>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
+        // (with a workgroup list the kernel's workgroups beyond the list return at once; launched all the same they are ~100,000
+        // waves of a config-2 frame that only start and stop)
+        case RTK_TRACE_GROUP4: return launch_render_mode<RTK_TRACE_WAVE, 4>(A, (n_workgroups != 0u && n_workgroups < waves) ? n_workgroups : (unsigned)waves,
+                                                                            stats, forks, lds, lds_bytes, s);
         case RTK_TRACE_GROUP8: return launch_render_mode<RTK_TRACE_WAVE, 8>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
         case RTK_TRACE_GROUP16: return launch_render_mode<RTK_TRACE_WAVE, 16>(A, (unsigned)waves, stats, forks, lds, lds_bytes, s);
         default: return launch_render_mode<RTK_TRACE_AUTO, 1>(A, packed, stats, forks, lds, lds_bytes, s);

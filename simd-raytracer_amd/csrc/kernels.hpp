@@ -114,7 +114,8 @@ struct AssembleArgs {
 }  // namespace dev
 
 hipError_t launch_intersect(const dev::IntersectArgs &A, int mode, bool stats, hipStream_t s);
-hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool forks, hipStream_t s);
+// n_workgroups (GROUP modes with a workgroup list): how many workgroups the list holds, when the host knows; 0 = one per pixel block
+hipError_t launch_render(const dev::RenderArgs &A, int mode, bool stats, bool forks, hipStream_t s, unsigned n_workgroups = 0);
 // order[0..n) = the pixel blocks sorted by cost[], most expensive first (one workgroup, counting sort over 256 log-scale bins;
 // blocks cheaper than floor_below are not ordered among themselves).  Blocks costlier than light_below (units of 16 cycles;
 // 0 = all) get a workgroup each, the rest are packed `pack` to a workgroup; wg_list[0..hdr[0]) = the workgroups by expected

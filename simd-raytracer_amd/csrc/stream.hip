@@ -89,6 +89,10 @@ __device__ __forceinline__ void bin_count(uint32_t *bins, const uint32_t key, co
 // Dynamic work distribution for the queue-driven stages: a unit's first item is its own index, every further item
 // is drawn from an atomic ticket, so the stage ends when the queue is empty rather than when the unluckiest static
 // share is done.
+// waves per SIMD the trace kernels are built for (= their register budget: 8 -> 64 VGPRs, 6 -> 80, 5 -> 96, 4 -> 128)
+#ifndef RTK_STREAM_WAVES
+#define RTK_STREAM_WAVES 8
+#endif
 #ifndef RTK_TICKET_ITEMS
 #define RTK_TICKET_ITEMS 4
 #endif
@@ -171,7 +175,7 @@ __device__ __forceinline__ void store_ray(RayRec *dst, const V3 o, const V3 d, c
 // k_path: LEVEL0 = camera rays, one work unit per 8x8 pixel block (same bucket / rank mapping as k_render);
 // otherwise the depth-`level` nodes, units of 64 consecutive nodes drawn from a ticket.
 template <bool LEVEL0, bool STATS, int SLICES, int MODE>
-__global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
+__global__ __launch_bounds__(256, RTK_STREAM_WAVES) void k_path(StreamArgs S) {
     const RenderArgs &A = S.r;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256, 8) void k_path(StreamArgs S) {
 // k_shadow: item = (group of 64 shading points of depth `level`, light).  Light loop body of render.hpp:184-206 up
 // to the occlusion decision (is_occluded, :110-131); the contribution is stored and summed in light order later.
 template <bool STATS, int SLICES, int MODE>
-__global__ __launch_bounds__(256, 8) void k_shadow(StreamArgs S) {
+__global__ __launch_bounds__(256, RTK_STREAM_WAVES) void k_shadow(StreamArgs S) {
     const RenderArgs &A = S.r;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
