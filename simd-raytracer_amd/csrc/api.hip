@@ -59,6 +59,8 @@ struct rtk_knobs {
     bool batch_scalar_surv = false;                         // RTK_BATCH_SCALAR_SURV: the same in the batched intersect
     bool stream_scalar_surv = true;                         // RTK_STREAM_SCALAR_SURV: survivors through the scalar cache in the streaming kernels
     bool repack = true;                                     // RTK_REPACK: RTK_TRACE_AUTO may sort large incoherent ray batches
+    bool raster_tiles = true;                               // RTK_RASTER_TILES: coherent batches that are rows of camera rays go to the waves as 8x8 blocks
+    int repack_skip_bits = 6;                               // RTK_REPACK_SKIP_BITS: low key bits left unsorted when <= 3 dimensions vary (0..14)
     int repack_trace = -1;                                  // RTK_REPACK_TRACE: strategy for a sorted batch (0 auto, 1 lane, 2 wave; default: by the probe)
     size_t group8_below = 9000;                             // RTK_GROUP8_BELOW_BLOCKS
     int stream_node_factor = 0;                             // RTK_STREAM_NODE_FACTOR (0 = default)
@@ -88,6 +90,8 @@ struct rtk_knobs {
         if (geti("RTK_LIGHT_BELOW_CYCLES", v) && v >= 0) k.light_cycles = uint32_t(v);
         if (geti("RTK_ORDER_FLOOR_CYCLES", v) && v >= 0) k.order_floor_cycles = uint32_t(v);
         if (geti("RTK_REPACK", v)) k.repack = v != 0;
+        if (geti("RTK_RASTER_TILES", v)) k.raster_tiles = v != 0;
+        if (geti("RTK_REPACK_SKIP_BITS", v) && v >= 0 && v <= 14) k.repack_skip_bits = int(v);
         if (geti("RTK_STREAM_SCALAR_SURV", v)) k.stream_scalar_surv = v != 0;
         if (geti("RTK_BATCH_SCALAR_SURV", v)) k.batch_scalar_surv = v != 0;
         if (geti("RTK_REPACK_TRACE", v) && (v == RTK_TRACE_AUTO || v == RTK_TRACE_WAVE || v == RTK_TRACE_LANE)) k.repack_trace = int(v);
@@ -171,6 +175,8 @@ struct rtk_accel {
     // ray repacking workspace (batched intersect, repack.hip)
     uint32_t *rp_bounds = nullptr, *rp_keys = nullptr, *rp_idx = nullptr;
     void *rp_temp = nullptr;
+    uint32_t *rp_host = nullptr;     // pinned: the probe's words as the host sees them
+    hipEvent_t rp_probe_ev = nullptr;
     hipEvent_t rp_done = nullptr;    // recorded behind the k_intersect that walks rp_idx: the next repack on any stream waits for it
     bool rp_in_use = false;
     size_t rp_temp_bytes = 0, rp_cap = 0;
@@ -594,6 +600,8 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipFree(a->fb_cost); (void)hipFree(a->fb_order); (void)hipFree(a->fb_bins);
         for (auto &e : a->trial_ev) if (e) (void)hipEventDestroy(e);
         if (a->rp_done) (void)hipEventDestroy(a->rp_done);
+        if (a->rp_probe_ev) (void)hipEventDestroy(a->rp_probe_ev);
+        if (a->rp_host) (void)hipHostFree(a->rp_host);
         if (a->fb_nwgs_ev) (void)hipEventDestroy(a->fb_nwgs_ev);
         if (a->fb_nwgs_host) (void)hipHostFree(a->fb_nwgs_host);
     }
@@ -625,7 +633,7 @@ static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, 
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) return fail(RTK_ERR_INVALID, "hit buffer must be 16-byte aligned");
     dev::IntersectArgs A;
     A.tree = tree_view(a);
-    A.rays = d_rays; A.out = d_out; A.n = n; A.cull = cull ? 1 : 0; A.counters = a->d_counters; A.perm = nullptr;
+    A.rays = d_rays; A.out = d_out; A.n = n; A.cull = cull ? 1 : 0; A.counters = a->d_counters; A.perm = nullptr; A.raster_w = 0u; A.verdict = nullptr;
     A.tree.scalar_surv = a->knobs.batch_scalar_surv ? 1 : 0;
     // Ray repacking (repack.hip).  Large batches are probed first (every 16th wave; one stream synchronisation): waves that are
     // coherent as they come are walked wave-cooperatively; a batch in no useful order is sorted by origin / direction cell and
@@ -646,22 +654,42 @@ static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, 
         if (a->rp_in_use) RTK_HIP(hipStreamWaitEvent(s, a->rp_done, 0));
         hipError_t eb = hipSuccess;
         bool sort = forced;
+        unsigned sort_from_bit = 0u;
         int sorted_mode = RTK_TRACE_AUTO;                                    // any order: wave-cooperative with the per-lane fallback
         if (probe) {
             // AUTO: the probe's verdict is needed on the host (one stream synchronisation; RTK_TRACE_REPACK and RTK_REPACK=0 never block)
-            eb = launch_ray_bounds(d_rays, n, a->rp_bounds, 16u, s);
+            // The verdict is made on the device (k_raster_probe) and needed on the host; while it travels, the launch a coherent
+            // batch needs is already under way -- it reads the same verdict and does nothing if the batch is to be sorted.
+            const uint32_t probe_stride = uint32_t(((n + 63) / 64 + 4095) / 4096 > 16 ? ((n + 63) / 64 + 4095) / 4096 : 16);   // ~4,096 waves looked at
+            eb = launch_ray_bounds(d_rays, n, a->rp_bounds, probe_stride, s);
+            if (eb == hipSuccess) eb = launch_raster_probe(d_rays, n, a->rp_bounds, a->knobs.raster_tiles, s);
             if (eb != hipSuccess) return hip_fail(eb, "launch k_ray_bounds (probe)");
-            uint32_t h[kRepackBoundsWords];
-            RTK_HIP(hipMemcpyAsync(h, a->rp_bounds, sizeof(h), hipMemcpyDeviceToHost, s));
-            RTK_HIP(hipStreamSynchronize(s));
-            const RepackProbe pr = decode_probe(h);
-            sort = pr.wide_dir_fraction >= 0.25f || pr.origin_spread >= 0.25f;
-            if (pr.active_dims <= 3) sorted_mode = RTK_TRACE_WAVE;           // ten bits per dimension: the sort makes tight waves
-            if (!sort) mode = RTK_TRACE_WAVE;                                // coherent as it comes
+            if (!a->rp_host) {
+                RTK_HIP(hipHostMalloc(reinterpret_cast<void **>(&a->rp_host), kRepackBoundsWords * sizeof(uint32_t), hipHostMallocDefault));
+                RTK_HIP(hipEventCreateWithFlags(&a->rp_probe_ev, hipEventDisableTiming));
+            }
+            uint32_t *h = a->rp_host;
+            RTK_HIP(hipMemcpyAsync(h, a->rp_bounds, kRepackBoundsWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            RTK_HIP(hipEventRecord(a->rp_probe_ev, s));
+            {
+                dev::IntersectArgs Spec = A;
+                Spec.verdict = a->rp_bounds;
+                const hipError_t es = launch_intersect(Spec, RTK_TRACE_WAVE, false, s);
+                if (es != hipSuccess) return hip_fail(es, "launch k_intersect");
+                RTK_HIP(hipEventRecord(a->rp_done, s));                     // (it reads the workspace's verdict words)
+                a->rp_in_use = true;
+            }
+            RTK_HIP(hipEventSynchronize(a->rp_probe_ev));                   // the verdict, not the trace
+            sort = h[16] != 0u;
+            if (!sort) return RTK_OK;                                        // coherent as it comes: that launch was the batch
+            if (h[17] <= 3u) {
+                sorted_mode = RTK_TRACE_WAVE;                                // ten bits per dimension: the sort makes tight waves
+                sort_from_bit = uint32_t(a->knobs.repack_skip_bits);         // ... also when the last two of the ten stay unsorted: a radix pass less
+            }
         }
         if (sort) {
             eb = launch_ray_bounds(d_rays, n, a->rp_bounds, 1u, s);
-            if (eb == hipSuccess) eb = launch_ray_sort(d_rays, n, a->rp_bounds, a->rp_keys, a->rp_idx, a->rp_temp, a->rp_temp_bytes, s);
+            if (eb == hipSuccess) eb = launch_ray_sort(d_rays, n, a->rp_bounds, a->rp_keys, a->rp_idx, a->rp_temp, a->rp_temp_bytes, s, sort_from_bit);
             if (eb != hipSuccess) return hip_fail(eb, "ray repacking");
             A.perm = a->rp_idx + n;
             mode = a->knobs.repack_trace >= 0 ? a->knobs.repack_trace : sorted_mode;
@@ -813,7 +841,9 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             }
         }
     }
-    if (trial_start) RTK_HIP(hipEventRecord(trial_start, s));
+    // (the streaming pipeline's trial is started behind its workspace allocation, below: tens of GB of hipMalloc in front of the
+    // first frame once made the megakernel "win" config 5's shape at 1.2 s a frame against 0.1)
+    if (trial_start && !stream) RTK_HIP(hipEventRecord(trial_start, s));
     const bool twopass = p->trace_mode == RTK_TRACE_TWOPASS;
     if (twopass && p->spp != 1) return fail(RTK_ERR_UNSUPPORTED, "RTK_TRACE_TWOPASS needs spp == 1");
     if (twopass) {
@@ -849,8 +879,16 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
         const int n_launch = (n_pass + batch - 1) / batch;
         int lanes = n_launch < a->knobs.stream_lanes ? n_launch : a->knobs.stream_lanes;     // batches in flight at once (stream.hpp)
         while (lanes > 1 && nodes_per_sample * size_t(batch) * bytes_per_node * size_t(lanes) > budget) lanes -= 1;
+        const size_t ws_nodes_before = a->ws_nodes;
+        const int ws_lanes_before = a->ws_lanes;
         rc = ensure_stream_ws(a, out_pixels, nodes_per_sample * size_t(batch), a->scene.lights.size(), p->spp > 1, lanes);
         if (rc != RTK_OK) return rc;
+        if (trial_start && (a->ws_nodes != ws_nodes_before || a->ws_lanes != ws_lanes_before)) {
+            // fresh queues: their first use is not what a frame costs -- time the pipeline on the next frame instead
+            trial_start = trial_end = nullptr;
+            a->trial_state = 0;
+        }
+        if (trial_start) RTK_HIP(hipEventRecord(trial_start, s));
         dev::StreamArgs S;
         S.r = A; S.r.tree.scalar_surv = a->knobs.stream_scalar_surv ? 1 : 0; S.ws = a->ws;
         S.key_dirs = p->diffuse_rays > 0 ? 1u : 0u; S.level = 0; S.sample = 0; S.n_batch = 1; S.n_root = uint32_t(n_root); S.n_level0 = uint32_t(n_root); S.auto_min_lanes = a->knobs.auto_min_lanes;

@@ -44,7 +44,23 @@ __global__ __launch_bounds__(256) void k_intersect(IntersectArgs A) {
 
     const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = slot < A.n;
-    const size_t i = (active && A.perm != nullptr) ? (size_t)A.perm[slot] : slot;      // repacked batches: the ray this slot was dealt
+    size_t i = (active && A.perm != nullptr) ? (size_t)A.perm[slot] : slot;            // repacked batches: the ray this slot was dealt
+    uint32_t raster_w = A.raster_w;
+    if (A.verdict != nullptr) {                                                        // (wave-uniform scalar loads)
+        if (A.verdict[16] != 0u) return;                                               // to be sorted: the host launches again
+        raster_w = A.verdict[15];
+        if (raster_w < 64u || (raster_w & 7u) != 0u || (size_t)raster_w * 16u > A.n) raster_w = 0u;
+    }
+    if (raster_w != 0u) {
+        // a raster of rows: bands of 8 rows are dealt as 8x8 blocks, one per wave; what is left over after the last whole band stays as it is
+        const size_t band = (size_t)raster_w * 8u;
+        const size_t tiled = (A.n / band) * band;
+        if (slot < tiled) {
+            const size_t b = slot / band;
+            const uint32_t within = (uint32_t)(slot % band), tile = within >> 6, l = within & 63u;
+            i = (b * 8u + (l >> 3)) * (size_t)raster_w + (size_t)tile * 8u + (l & 7u);
+        }
+    }
     Ray r;
     if (active) {
         const float *p = reinterpret_cast<const float *>(A.rays + i);

@@ -48,6 +48,9 @@ struct IntersectArgs {
     rtk_hit *out;
     size_t n;
     const uint32_t *perm;             // lane i takes ray perm[i] and writes hit perm[i] (repack.hip); null = identity
+    uint32_t raster_w;                // != 0 (perm == null): the batch is rows of raster_w rays; waves take 8x8 blocks of it (k_raster_probe)
+    const uint32_t *verdict;          // non-null: a launch made BEFORE the host knows the probe's verdict (repack.hpp words 15-17, on the
+                                      // device): it does nothing if the batch is to be sorted, and takes the raster width from there
     int cull;
     unsigned long long *counters;
 };

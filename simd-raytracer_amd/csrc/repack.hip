@@ -48,6 +48,10 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // bounds[12] counts the sampled waves whose own directions are far apart (the coherence probe of RTK_TRACE_AUTO), bounds[13] the
 // sampled waves, bounds[14] (a float) sums the extents of the waves' origins.  Grid-stride over the sampled waves, minima / maxima kept per lane, ONE set of atomics per workgroup (one per
 // wave of 64 rays, the first version, spent 10 ms on 65,536 x 14 atomics to the same fourteen words).
+__global__ void k_bounds_init(uint32_t *bounds) {
+    if (threadIdx.x < (unsigned)kRepackBoundsWords) bounds[threadIdx.x] = threadIdx.x < 6u ? 0xFFFFFFFFu : 0u;
+}
+
 template <bool PROBE>
 __global__ __launch_bounds__(256) void k_ray_bounds(const rtk_ray *rays, size_t n, uint32_t *bounds, uint32_t wave_stride) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -107,6 +111,68 @@ __global__ __launch_bounds__(256) void k_ray_bounds(const rtk_ray *rays, size_t 
     else if (PROBE && threadIdx.x == 14u) atomicAdd(reinterpret_cast<float *>(bounds + 14), sh_osum);   // sum of the waves' origin extents
 }
 
+// Is the batch a row-major RASTER of rays (the camera rays of a frame, row after row)?  Then a wave of 64 consecutive rays is a
+// 64x1 strip of pixels, and the triangles such a strip can touch are twice those of an 8x8 block: dealt to the waves as 8x8
+// blocks (k_intersect, IntersectArgs::raster_w) the same batch runs in half the time (2^24 camera rays on hw09/scene5: 0.545 ->
+// 0.303 ms).  One workgroup looks at the first rays: the step between neighbours is small and regular, and every W-th step is a
+// jump (the end of a row).  out[0] = W (a multiple of 8, >= 64, at least 16 rows seen), else 0.  Only lane placement depends on
+// it -- a wrong guess costs speed, never a result.
+// ... and the probe's verdict, on the device (the host reads the same words): bounds[16] = 1 when the batch comes in no useful
+// order and is to be sorted (the criteria of RTK_TRACE_AUTO: a quarter of the probed waves with directions more than 0.25 apart, or
+// origins spread over a quarter of the batch's extent), bounds[17] = how many of the six ray coordinates vary at all.
+__device__ void probe_verdict(uint32_t *bounds) {
+    auto k2f = [](uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); };
+    float scale = 0.0f, ext[6], oext = 0.0f;
+    for (int k = 0; k < 6; ++k) {
+        const float lo = k2f(bounds[k]), hi = k2f(bounds[6 + k]);
+        ext[k] = hi - lo;
+        scale = __builtin_fmaxf(scale, __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi)));
+    }
+    uint32_t dims = 0u;
+    for (int k = 0; k < 6; ++k)
+        if (ext[k] > 1.0e-6f * scale && ext[k] < 1.0e30f) { dims += 1u; if (k < 3 && ext[k] > oext) oext = ext[k]; }
+    const uint32_t waves = bounds[13];
+    const float wide = waves ? (float)bounds[12] / (float)waves : 0.0f;
+    const float spread = (waves && oext > 0.0f) ? (__uint_as_float(bounds[14]) / (float)waves) / oext : 0.0f;
+    bounds[16] = (wide >= 0.25f || spread >= 0.25f) ? 1u : 0u;
+    bounds[17] = dims;
+}
+
+__global__ __launch_bounds__(256) void k_raster_probe(const rtk_ray *rays, size_t n, uint32_t *bounds, uint32_t want_raster) {
+    uint32_t *out = bounds + 15;
+    if (threadIdx.x == 0u) probe_verdict(bounds);
+    if (want_raster == 0u) { if (threadIdx.x == 0u) out[0] = 0u; return; }
+    __shared__ float s_step0;
+    __shared__ uint32_t s_first, s_bad;
+    constexpr uint32_t kLook = 16384;
+    const uint32_t m = n < kLook ? (uint32_t)n : kLook;
+    auto dir_step = [&](uint32_t i, uint32_t j) {
+        const float *a = reinterpret_cast<const float *>(rays + i), *b = reinterpret_cast<const float *>(rays + j);
+        const float s = (__builtin_fabsf(a[3] - b[3]) + __builtin_fabsf(a[4] - b[4])) + __builtin_fabsf(a[5] - b[5]);
+        return (s == s) ? s : 1.0e30f;
+    };
+    if (threadIdx.x == 0u) { s_step0 = m >= 2u ? dir_step(0u, 1u) : 0.0f; s_first = 0xFFFFFFFFu; s_bad = 0u; }
+    __syncthreads();
+    const float s0 = s_step0;
+    if (!(s0 > 0.0f && s0 < 0.05f)) { if (threadIdx.x == 0u) out[0] = 0u; return; }      // neighbours are not neighbours
+    for (uint32_t c = 64u + 8u * threadIdx.x; c < m; c += 8u * blockDim.x)               // the first jump: the end of row 0 (a multiple of 8)
+        if (dir_step(c - 1u, c) > 8.0f * s0) atomicMin(&s_first, c);
+    __syncthreads();
+    const uint32_t W = s_first;
+    if (W == 0xFFFFFFFFu || W < 64u || (W & 7u) != 0u || (size_t)W * 16u > n) { if (threadIdx.x == 0u) out[0] = 0u; return; }
+    // 16 rows: steps inside a row stay small, rows end where they should, and a ray lies next to the one W before it
+    for (uint32_t k = threadIdx.x; k < 16u * 32u; k += blockDim.x) {
+        const uint32_t row = k >> 5, x = (uint32_t)(((size_t)(k & 31u) * (W - 2u)) / 31u);
+        const uint32_t i = row * W + x;
+        bool ok = dir_step(i, i + 1u) < 4.0f * s0;
+        if (row > 0u) ok = ok && dir_step(i, i - W) < 8.0f * s0;
+        ok = ok && ((k & 31u) != 31u || (size_t)(row + 1u) * W >= n || dir_step(row * W + W - 1u, row * W + W) > 8.0f * s0);
+        if (!ok) atomicAdd(&s_bad, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) out[0] = s_bad == 0u ? W : 0u;
+}
+
 // key[i] = Morton code of ray i's cell, idx[i] = i
 __global__ __launch_bounds__(256) void k_ray_keys(const rtk_ray *rays, size_t n, const uint32_t *bounds, uint32_t *keys, uint32_t *idx) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,9 +217,8 @@ __global__ __launch_bounds__(256) void k_ray_keys(const rtk_ray *rays, size_t n,
 }  // namespace dev
 
 hipError_t launch_ray_bounds(const rtk_ray *d_rays, size_t n, uint32_t *d_bounds, uint32_t wave_stride, hipStream_t s) {
-    static const uint32_t init[kRepackBoundsWords] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    hipError_t e = hipMemcpyAsync(d_bounds, init, sizeof(init), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return e;
+    // (set on the device: a copy from pageable host memory is staged synchronously, ~20 us in front of every probe)
+    hipLaunchKernelGGL(dev::k_bounds_init, dim3(1), dim3(64), 0, s, d_bounds);
     if (wave_stride == 0u) wave_stride = 1u;
     const size_t waves = (n + 63) / 64;
     const size_t sampled = (waves + wave_stride - 1) / wave_stride;
@@ -162,6 +227,11 @@ hipError_t launch_ray_bounds(const rtk_ray *d_rays, size_t n, uint32_t *d_bounds
     if (blocks > 2048) blocks = 2048;                                       // grid-stride: 8 workgroups per CU
     if (wave_stride > 1u) hipLaunchKernelGGL(dev::k_ray_bounds<true>, dim3((unsigned)blocks), dim3(256), 0, s, d_rays, n, d_bounds, wave_stride);
     else hipLaunchKernelGGL(dev::k_ray_bounds<false>, dim3((unsigned)blocks), dim3(256), 0, s, d_rays, n, d_bounds, wave_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster_probe(const rtk_ray *d_rays, size_t n, uint32_t *d_bounds, bool want_raster, hipStream_t s) {
+    hipLaunchKernelGGL(dev::k_raster_probe, dim3(1), dim3(256), 0, s, d_rays, n, d_bounds, want_raster ? 1u : 0u);
     return hipGetLastError();
 }
 
@@ -191,13 +261,14 @@ hipError_t repack_temp_bytes(size_t n, size_t *bytes) {
 }
 
 hipError_t launch_ray_sort(const rtk_ray *d_rays, size_t n, const uint32_t *d_bounds, uint32_t *d_keys /* [2n] */, uint32_t *d_idx /* [2n] */,
-                           void *d_temp, size_t temp_bytes, hipStream_t s) {
+                           void *d_temp, size_t temp_bytes, hipStream_t s, unsigned begin_bit) {
     if (n == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(dev::k_ray_keys, dim3(blocks), dim3(256), 0, s, d_rays, n, d_bounds, d_keys, d_idx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys + n, d_idx, d_idx + n, n, 0u, 30u, s);   // sorted indices: d_idx + n
+    // (begin_bit > 0: the key's lowest bits are left unsorted -- a radix pass less; rays that differ only there are neighbours anyway)
+    return rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys + n, d_idx, d_idx + n, n, begin_bit < 30u ? begin_bit : 0u, 30u, s);   // sorted indices: d_idx + n
 }
 
 }  // namespace rtk

@@ -372,7 +372,7 @@ def test_cost_feedback_reorders_blocks_but_not_results(rtk, ora, mode):
     cfg = rtk.RenderConfig(width=333, height=190, max_ray_depth=5, trace_mode=FRAME_MODES[mode])
     other = rtk.RenderConfig(width=100, height=60, max_ray_depth=5, trace_mode=FRAME_MODES[mode])
     ref_other, _ = oacc.render(100, 60, 1, 5, 0)
-    for i in range(11):                                             # the order is rebuilt from fresh costs every 8th frame
+    for i in range(11):                                             # the first frame's order comes from the camera-ray prior, the second's from measured costs, then every 16th is re-sorted
         rgb, cn = acc.render_frame(cfg)
         assert cn["rays"] == ocn["rays"], i
         assert np.array_equal(_bits(rgb), _bits(ref)), i
@@ -466,3 +466,27 @@ def test_bad_arguments_are_reported_not_thrown(rtk):
         acc.render_frame(rtk.RenderConfig(spp=0))
     with pytest.raises(rtk.RtkError):
         acc.intersect(np.zeros((4, 6), np.float32), True, trace_mode=17)
+
+
+def test_raster_batches_are_dealt_as_8x8_blocks_without_changing_a_bit(rtk, ora):
+    """RTK_TRACE_AUTO on a large coherent batch that is rows of camera rays (k_raster_probe finds the row length) hands 8x8 pixel
+    blocks to the waves instead of 64x1 strips.  Lane placement only: every hit is where the caller's order puts it, same bits
+    as RTK_TRACE_WAVE on the plain order -- for whole frames tiled, a ragged tail, a width that is no multiple of 8 (no tiling),
+    and a batch that only looks like a raster at its start."""
+    import torch
+
+    acc, _ = _scene_pair(rtk, ora, SCENE5)
+    st = torch.cuda.current_stream().cuda_stream
+    for (w, h, n) in [(1920, 1080, 1920 * 1080 + 1920 * 3 + 77), (640, 360, 640 * 360 * 2), (333, 400, 333 * 400 * 3)]:
+        cfg = rtk.RenderConfig(width=w, height=h)
+        cam = torch.empty((w * h, 6), dtype=torch.float32, device="cuda")
+        acc.camera_rays_device(cfg, cam.data_ptr(), 0, st)
+        rays = cam.repeat(-(-n // (w * h)), 1)[:n].contiguous()
+        if n >= 1 << 20:                                            # a tail that stops looking like the raster
+            rays[-50_000:] = rays[torch.randperm(n, device="cuda")[:50_000]]
+        want = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+        got = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+        acc.intersect_device(rays.data_ptr(), n, True, want.data_ptr(), rtk.TRACE_WAVE, st)
+        acc.intersect_device(rays.data_ptr(), n, True, got.data_ptr(), rtk.TRACE_AUTO, st)
+        torch.cuda.synchronize()
+        assert torch.equal(want, got), (w, h, n)
