@@ -33,4 +33,4 @@ for world in [int(w) for w in os.environ.get("TC_WORLDS", "1 2 4 8").split()]:
             rays.append(acc.last_counters()["rays"])
         if world == 1: base[mode] = max(times)
         print(f"world {world} mode {mode}: slowest rank {max(times):.3f} ms, fastest {min(times):.3f} ms, rays/rank {min(rays)}..{max(rays)}, "
-              f"kernel-only scaling {base[mode] / max(times):.2f}x", flush=True)
+              f"kernel-only scaling {base.get(mode, max(times)) / max(times):.2f}x", flush=True)
