@@ -239,6 +239,33 @@ dev::TreeView tree_view(const rtk_accel *a) {
 
 // (Re)allocates the streaming workspace for `pixels` output pixels.  Allocation synchronises the device, so it only
 // happens when a larger frame (or more lights / multi-sample) is requested than ever before on this accel.
+// The streams the streaming pipeline's lanes (and their k_shadow side kernels) run on belong to the PROCESS and are made once
+// per device, in the order the first accel needs them.  HIP deals a process's streams to a handful of hardware queues; lanes
+// that land on one queue take turns instead of overlapping, and which queue a stream gets depends on how many were made before
+// it.  With streams made (and destroyed) per accel, the second accel of a process ran the same kernels on the same rays up to
+// 60 % slower (hw11/scene8 23 -> 37 ms, hw15/scene2 47 -> 58 ms per pass; GPU_MAX_HW_QUEUES=2: 72 ms): its lanes shared queues.
+struct LaneStreams {
+    hipStream_t lane[rtk::dev::kStreamLanes] = {};
+    hipStream_t side[rtk::dev::kStreamLanes][2] = {};
+};
+std::mutex g_lane_mu;
+LaneStreams g_lane_streams[16];
+
+hipError_t lane_streams_for(int device, int lanes, LaneStreams **out) {
+    if (device < 0 || device >= 16) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_lane_mu);
+    LaneStreams &L = g_lane_streams[device];
+    for (int j = 0; j < lanes && j < rtk::dev::kStreamLanes; ++j) {
+        hipError_t e = hipSuccess;
+        if (j > 0 && !L.lane[j]) e = hipStreamCreateWithFlags(&L.lane[j], hipStreamNonBlocking);
+        for (int par = 0; par < 2 && e == hipSuccess; ++par)
+            if (!L.side[j][par]) e = hipStreamCreateWithFlags(&L.side[j][par], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *out = &L;
+    return hipSuccess;
+}
+
 void free_stream_ws(rtk_accel *a) {
     (void)hipFree(a->ws.sumbuf);
     for (int j = 0; j < dev::kStreamLanes; ++j) {
@@ -279,15 +306,21 @@ int ensure_stream_ws(rtk_accel *a, size_t pixels, size_t nodes, size_t lights, b
         RTK_HIP(hipMalloc(reinterpret_cast<void **>(&w.hit_order), nh * sizeof(uint32_t)));
         w.sumbuf = sumbuf;
         w.node_cap = uint32_t(nn); w.hit_cap = uint32_t(nh);
-        if (j > 0 && !a->lane_stream[j]) RTK_HIP(hipStreamCreateWithFlags(&a->lane_stream[j], hipStreamNonBlocking));
         if (!a->lane_done[j]) RTK_HIP(hipEventCreateWithFlags(&a->lane_done[j], hipEventDisableTiming));
         for (int par = 0; par < 2; ++par) {
-            if (!a->lane_side[j].stream[par]) RTK_HIP(hipStreamCreateWithFlags(&a->lane_side[j].stream[par], hipStreamNonBlocking));
             if (!a->lane_side[j].ready[par]) RTK_HIP(hipEventCreateWithFlags(&a->lane_side[j].ready[par], hipEventDisableTiming));
             if (!a->lane_side[j].done[par]) RTK_HIP(hipEventCreateWithFlags(&a->lane_side[j].done[par], hipEventDisableTiming));
         }
     }
     if (!a->lane_fork) RTK_HIP(hipEventCreateWithFlags(&a->lane_fork, hipEventDisableTiming));
+    {   // the process's lane streams (see LaneStreams); the events that order them stay this accel's own
+        LaneStreams *L = nullptr;
+        RTK_HIP(lane_streams_for(a->device, nlanes, &L));
+        for (int j = 0; j < nlanes; ++j) {
+            a->lane_stream[j] = L->lane[j];
+            a->lane_side[j].stream[0] = L->side[j][0]; a->lane_side[j].stream[1] = L->side[j][1];
+        }
+    }
     a->ws = a->ws_lane[0];
     a->ws_lanes = nlanes; a->ws_pixels = np; a->ws_nodes = nn; a->ws_lights = nl; a->ws_sum = sum;
     return RTK_OK;
@@ -586,12 +619,11 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
         (void)hipFree(a->d_textures); (void)hipFree(a->d_tri_uv); (void)hipFree(a->d_tex_pixels); (void)hipFree(a->d_leaves_fast);
         free_stream_ws(a);
-        for (auto &st : a->lane_stream) if (st) (void)hipStreamDestroy(st);
+        // (the lane and side streams are the process's: LaneStreams)
         for (auto &e : a->lane_done) if (e) (void)hipEventDestroy(e);
         if (a->lane_fork) (void)hipEventDestroy(a->lane_fork);
         for (auto &sd : a->lane_side)
             for (int par = 0; par < 2; ++par) {
-                if (sd.stream[par]) (void)hipStreamDestroy(sd.stream[par]);
                 if (sd.ready[par]) (void)hipEventDestroy(sd.ready[par]);
                 if (sd.done[par]) (void)hipEventDestroy(sd.done[par]);
             }

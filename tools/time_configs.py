@@ -19,6 +19,7 @@ names = {0: "auto", 1: "lane", 2: "wave", 3: "group4", 6: "stream", 7: "twopass"
 only = sys.argv[1:] 
 for cname, (path, kw) in CASES.items():
     if only and not any(o in cname for o in only): continue
+    time.sleep(float(os.environ.get("TC_SLEEP", "0")))
     acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(path))
     for mode in [int(m) for m in os.environ.get("TC_MODES", "0 1 2 3 6 7").split()]:
         cfg = rtk.RenderConfig(trace_mode=mode, **kw)
