@@ -191,9 +191,10 @@ def synthetic_extras(rtk, torch, dist, stream, rank: int, world: int) -> dict:
     """N = 2^24 rays through rtk_accel_intersect_device on scene5's tree.  At world > 1 the batch is cut into
     contiguous ray ranges, one per rank, and the 32-byte hits are all-gathered over RCCL inside the timed region; the time of a
     launch is the slowest rank's.  The path has no other exchange step: rays are independent."""
+    par = importlib.import_module("simd-raytracer_amd.parallel")
     n = 1 << 24
     acc, sets = synthetic_rays(rtk, torch, stream, n)
-    lo, hi = rank * n // world, (rank + 1) * n // world
+    lo, hi = par.ray_range(n, rank, world)
     m = hi - lo
     hits = torch.empty((n, 32), dtype=torch.uint8, device="cuda")            # the gathered result (rank order == ray order)
     mine = hits[lo:hi] if world == 1 else torch.empty((m, 32), dtype=torch.uint8, device="cuda")
@@ -206,7 +207,7 @@ def synthetic_extras(rtk, torch, dist, stream, rank: int, world: int) -> dict:
             def launch():
                 acc.intersect_device(part.data_ptr(), m, cull, mine.data_ptr(), mode, stream.cuda_stream)
                 if world > 1:
-                    dist.all_gather_into_tensor(hits.view(-1), mine.view(-1))
+                    par.gather_hits(mine, n, rank, world, out=hits)
             for _ in range(2):
                 launch()
             ms = min(event_ms(torch, stream, launch, 1) for _ in range(5))

@@ -114,6 +114,36 @@ def gather_frame(local: torch.Tensor, layout: BucketLayout, accel=None, cfg=None
     return assemble_host(gathered, layout)
 
 
+def ray_range(n: int, rank: int, world: int) -> tuple:
+    """A batch of n independent rays cut into contiguous ranges, one per rank: [lo, hi) of `rank`.  Rank order == ray order, so an
+    all-gather of the ranks' hit arrays IS the batch's hit array -- when the ranges are equally long (n % world == 0), which is what
+    all_gather_into_tensor needs; otherwise gather_hits pads."""
+    return rank * n // world, (rank + 1) * n // world
+
+
+def gather_hits(mine: torch.Tensor, n: int, rank: int, world: int, out: torch.Tensor | None = None, group=None) -> torch.Tensor:
+    """All-gather of the ranks' hit records ([hi - lo, 32] uint8 each, the ranges of ray_range) into the batch's [n, 32] array."""
+    import torch.distributed as dist
+
+    if out is None:
+        out = torch.empty((n, mine.shape[1]), dtype=mine.dtype, device=mine.device)
+    if world == 1:
+        out.copy_(mine)
+        return out
+    if n % world == 0:
+        dist.all_gather_into_tensor(out.view(-1), mine.reshape(-1), group=group)
+        return out
+    longest = -(-n // world)                                   # ragged ranges: equal-length padded pieces, cut back afterwards
+    padded = torch.zeros((longest, mine.shape[1]), dtype=mine.dtype, device=mine.device)
+    padded[: mine.shape[0]] = mine
+    pieces = torch.empty((world, longest, mine.shape[1]), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(pieces.view(-1), padded.view(-1), group=group)
+    for r in range(world):
+        lo, hi = ray_range(n, r, world)
+        out[lo:hi] = pieces[r, : hi - lo]
+    return out
+
+
 def render_sharded(accel, cfg, local: torch.Tensor, frame: torch.Tensor, gathered: torch.Tensor, group=None) -> torch.Tensor:
     """One sharded frame on the current CUDA stream: render this rank's buckets, all-gather, assemble."""
     stream = torch.cuda.current_stream().cuda_stream

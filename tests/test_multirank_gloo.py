@@ -86,6 +86,35 @@ def test_diagonal_deal_spreads_every_rank_over_all_columns():
     assert par.BucketLayout(1920, 1080, 64, 8).skew_q == 0
 
 
+def _hits_worker(rank, world, port, n, result_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        par = importlib.import_module("simd-raytracer_amd.parallel")
+        whole = (torch.arange(n * 32, dtype=torch.int64) * 2654435761 % 251).to(torch.uint8).view(n, 32)   # stands in for the hit records
+        lo, hi = par.ray_range(n, rank, world)
+        got = par.gather_hits(whole[lo:hi].clone(), n, rank, world)
+        np.save(os.path.join(result_dir, f"hits_{rank}.npy"), np.array([torch.equal(got, whole), hi - lo]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(1 << 12, 2), (1000, 3)])
+def test_sharded_ray_batch_gathers_into_ray_order(tmp_path, n, world):
+    """bench.py's synthetic workload at N > 1: contiguous ray ranges per rank, hits all-gathered (rank order == ray order); the
+    ragged case pads.  Same code path as on the GPUs (RCCL there, gloo here)."""
+    par = importlib.import_module("simd-raytracer_amd.parallel")
+    covered = [par.ray_range(n, r, world) for r in range(world)]
+    assert covered[0][0] == 0 and covered[-1][1] == n and all(covered[r][1] == covered[r + 1][0] for r in range(world - 1))
+    port = _free_port()
+    mp.spawn(_hits_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, m = np.load(tmp_path / f"hits_{r}.npy")
+        assert ok == 1 and m == covered[r][1] - covered[r][0]
+
+
 def _pipeline_worker(rank, world, port, frame_np, bucket, depth, n_frames, result_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
