@@ -61,6 +61,9 @@ struct rtk_knobs {
     bool repack = true;                                     // RTK_REPACK: RTK_TRACE_AUTO may sort large incoherent ray batches
     bool raster_tiles = true;                               // RTK_RASTER_TILES: coherent batches that are rows of camera rays go to the waves as 8x8 blocks
     int repack_skip_bits = 6;                               // RTK_REPACK_SKIP_BITS: low key bits left unsorted when <= 3 dimensions vary (0..14)
+    bool repack_full_bounds = false;                        // RTK_REPACK_FULL_BOUNDS: key cells from the bounds of all rays, not of a sample
+    int repack_skip_bits2 = 14;                             // RTK_REPACK_SKIP_BITS2: the same when <= 2 dimensions vary (0..22)
+    bool repack_dirs3 = false;                              // RTK_REPACK_DIRS3: directions enter the sort keys as three components even when all rays share an origin
     int repack_trace = -1;                                  // RTK_REPACK_TRACE: strategy for a sorted batch (0 auto, 1 lane, 2 wave; default: by the probe)
     size_t group8_below = 9000;                             // RTK_GROUP8_BELOW_BLOCKS
     int stream_node_factor = 0;                             // RTK_STREAM_NODE_FACTOR (0 = default)
@@ -91,6 +94,9 @@ struct rtk_knobs {
         if (geti("RTK_ORDER_FLOOR_CYCLES", v) && v >= 0) k.order_floor_cycles = uint32_t(v);
         if (geti("RTK_REPACK", v)) k.repack = v != 0;
         if (geti("RTK_RASTER_TILES", v)) k.raster_tiles = v != 0;
+        if (geti("RTK_REPACK_FULL_BOUNDS", v)) k.repack_full_bounds = v != 0;
+        if (geti("RTK_REPACK_SKIP_BITS2", v) && v >= 0 && v <= 22) k.repack_skip_bits2 = int(v);
+        if (geti("RTK_REPACK_DIRS3", v)) k.repack_dirs3 = v != 0;
         if (geti("RTK_REPACK_SKIP_BITS", v) && v >= 0 && v <= 14) k.repack_skip_bits = int(v);
         if (geti("RTK_STREAM_SCALAR_SURV", v)) k.stream_scalar_surv = v != 0;
         if (geti("RTK_BATCH_SCALAR_SURV", v)) k.batch_scalar_surv = v != 0;
@@ -644,7 +650,7 @@ void rtk_accel_destroy(rtk_accel *a) {
 
 // workspace of the ray repacking: keys and indices (double-buffered for the sort), rocPRIM's temporary storage; grows, never shrinks
 static int ensure_repack_ws(rtk_accel *a, size_t n) {
-    if (!a->rp_bounds) RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->rp_bounds), kRepackBoundsWords * sizeof(uint32_t)));
+    if (!a->rp_bounds) RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->rp_bounds), kRepackBoundsAlloc * sizeof(uint32_t)));
     if (a->rp_cap >= n) return RTK_OK;
     (void)hipFree(a->rp_keys); (void)hipFree(a->rp_idx); (void)hipFree(a->rp_temp);
     a->rp_keys = a->rp_idx = nullptr; a->rp_temp = nullptr; a->rp_cap = 0;
@@ -693,8 +699,9 @@ static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, 
             // The verdict is made on the device (k_raster_probe) and needed on the host; while it travels, the launch a coherent
             // batch needs is already under way -- it reads the same verdict and does nothing if the batch is to be sorted.
             const uint32_t probe_stride = uint32_t(((n + 63) / 64 + 4095) / 4096 > 16 ? ((n + 63) / 64 + 4095) / 4096 : 16);   // ~4,096 waves looked at
-            eb = launch_ray_bounds(d_rays, n, a->rp_bounds, probe_stride, s);
-            if (eb == hipSuccess) eb = launch_raster_probe(d_rays, n, a->rp_bounds, a->knobs.raster_tiles, s);
+            unsigned fold = 0;
+            eb = launch_ray_bounds(d_rays, n, a->rp_bounds, probe_stride, true, s, &fold);
+            if (eb == hipSuccess) eb = launch_raster_probe(d_rays, n, a->rp_bounds, a->knobs.raster_tiles, s, fold);
             if (eb != hipSuccess) return hip_fail(eb, "launch k_ray_bounds (probe)");
             if (!a->rp_host) {
                 RTK_HIP(hipHostMalloc(reinterpret_cast<void **>(&a->rp_host), kRepackBoundsWords * sizeof(uint32_t), hipHostMallocDefault));
@@ -715,13 +722,20 @@ static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, 
             sort = h[16] != 0u;
             if (!sort) return RTK_OK;                                        // coherent as it comes: that launch was the batch
             if (h[17] <= 3u) {
-                sorted_mode = RTK_TRACE_WAVE;                                // ten bits per dimension: the sort makes tight waves
-                sort_from_bit = uint32_t(a->knobs.repack_skip_bits);         // ... also when the last two of the ten stay unsorted: a radix pass less
+                sorted_mode = RTK_TRACE_WAVE;                                // ten or fifteen bits per dimension: the sort makes tight waves
+                // ... also when the lowest ones stay unsorted: one or two radix passes less (two dimensions: 8 of the 15 bits each)
+                sort_from_bit = h[17] <= 2u ? uint32_t(a->knobs.repack_skip_bits2) : uint32_t(a->knobs.repack_skip_bits);
             }
         }
         if (sort) {
-            eb = launch_ray_bounds(d_rays, n, a->rp_bounds, 1u, s);
-            if (eb == hipSuccess) eb = launch_ray_sort(d_rays, n, a->rp_bounds, a->rp_keys, a->rp_idx, a->rp_temp, a->rp_temp_bytes, s, sort_from_bit);
+            // The cells of the sort keys lie in the bounds of a SAMPLE of the batch (the probe's, where there was one; ~4,096 waves
+            // otherwise): a ray outside them lands in a border cell -- an order a little worse for it, never another result -- and a
+            // pass over all rays (0.13 ms of a 2^24-ray batch's 1.8) is saved.
+            if (!probe) {
+                const size_t waves = (n + 63) / 64;
+                eb = launch_ray_bounds(d_rays, n, a->rp_bounds, a->knobs.repack_full_bounds ? 1u : uint32_t((waves + 4095) / 4096), false, s);
+            } else if (a->knobs.repack_full_bounds) eb = launch_ray_bounds(d_rays, n, a->rp_bounds, 1u, false, s);
+            if (eb == hipSuccess) eb = launch_ray_sort(d_rays, n, a->rp_bounds, a->rp_keys, a->rp_idx, a->rp_temp, a->rp_temp_bytes, s, sort_from_bit, a->knobs.repack_dirs3);
             if (eb != hipSuccess) return hip_fail(eb, "ray repacking");
             A.perm = a->rp_idx + n;
             mode = a->knobs.repack_trace >= 0 ? a->knobs.repack_trace : sorted_mode;
