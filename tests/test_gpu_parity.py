@@ -490,3 +490,40 @@ def test_raster_batches_are_dealt_as_8x8_blocks_without_changing_a_bit(rtk, ora)
         acc.intersect_device(rays.data_ptr(), n, True, got.data_ptr(), rtk.TRACE_AUTO, st)
         torch.cuda.synchronize()
         assert torch.equal(want, got), (w, h, n)
+
+
+def test_sort_keys_of_the_repacking_cover_their_cases(rtk, ora):
+    """The key paths of csrc/repack.hip, each against the unsorted wave walk (same bits, caller's order): one origin with directions all
+    over the sphere (octahedral map incl. its folded hemisphere, a first ray that points along -x: negative pole), a few origins
+    (three-component direction cells), a size that ends in a partial 256-ray tile, and ray buffers that are only 8- and 4-byte aligned
+    (the float4 staging is skipped)."""
+    import torch
+
+    acc, oacc = _scene_pair(rtk, ora, SCENE5)
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(21)
+    n = (1 << 18) + 77
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[0] = (-1.0, 0.05, 0.02)
+    d[5::1001] = 0.0                                                 # zero directions: NaN keys, misses
+    one = np.concatenate([np.tile(np.float32([0.3, 2.0, 1.5]), (n, 1)), d], axis=1)
+    few = one.copy(); few[:, 0] += rng.integers(0, 3, n).astype(np.float32) * 4.0
+    sets = {"one_origin_sphere": one, "few_origins": few}
+    for name, rays in sets.items():
+        for shift in (0, 2, 1):                                     # floats the ray buffer is shifted by: 16-, 8-, 4-byte aligned
+            flat = torch.zeros((n * 6 + 4,), dtype=torch.float32, device="cuda")
+            flat[shift:shift + n * 6] = torch.from_numpy(np.ascontiguousarray(rays, dtype=np.float32).reshape(-1)).cuda()
+            ptr = flat.data_ptr() + 4 * shift
+            want = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+            acc.intersect_device(ptr, n, False, want.data_ptr(), rtk.TRACE_WAVE, st)
+            for mode in (rtk.TRACE_AUTO, MODES["repack"]):
+                got = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+                acc.intersect_device(ptr, n, False, got.data_ptr(), mode, st)
+                torch.cuda.synchronize()
+                assert torch.equal(want, got), (name, shift, mode)
+        k = 30_000
+        o = oacc.intersect(np.ascontiguousarray(rays[:k], dtype=np.float32), False)
+        w = np.frombuffer(want.cpu().numpy().tobytes(), dtype=rtk.HIT_DTYPE)[:k]
+        assert np.array_equal(w["tri"], o["tri"]) and np.array_equal(_bits(w["t"]), _bits(o["t"])), name
+        assert (o["tri"] != 0xFFFFFFFF).sum() > 1000
