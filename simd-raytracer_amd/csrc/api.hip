@@ -693,6 +693,7 @@ static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, 
         hipError_t eb = hipSuccess;
         bool sort = forced;
         unsigned sort_from_bit = 0u;
+        bool keys_made = false;
         int sorted_mode = RTK_TRACE_AUTO;                                    // any order: wave-cooperative with the per-lane fallback
         if (probe) {
             // AUTO: the probe's verdict is needed on the host (one stream synchronisation; RTK_TRACE_REPACK and RTK_REPACK=0 never block)
@@ -715,9 +716,16 @@ static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, 
                 Spec.verdict = a->rp_bounds;
                 const hipError_t es = launch_intersect(Spec, RTK_TRACE_WAVE, false, s);
                 if (es != hipSuccess) return hip_fail(es, "launch k_intersect");
-                RTK_HIP(hipEventRecord(a->rp_done, s));                     // (it reads the workspace's verdict words)
                 a->rp_in_use = true;
             }
+            // ... and so are the keys a batch to be sorted needs (k_ray_keys returns at once if it is not): the verdict's trip to the
+            // host and the launches that follow it no longer leave the stream idle
+            if (!a->knobs.repack_full_bounds) {
+                eb = launch_ray_keys(d_rays, n, a->rp_bounds, a->rp_keys, a->rp_idx, s, a->knobs.repack_dirs3, true);
+                if (eb != hipSuccess) return hip_fail(eb, "launch k_ray_keys");
+                keys_made = true;
+            }
+            RTK_HIP(hipEventRecord(a->rp_done, s));                         // (both read the workspace's verdict words)
             RTK_HIP(hipEventSynchronize(a->rp_probe_ev));                   // the verdict, not the trace
             sort = h[16] != 0u;
             if (!sort) return RTK_OK;                                        // coherent as it comes: that launch was the batch
@@ -735,7 +743,8 @@ static int intersect_device_impl(rtk_accel *a, const rtk_ray *d_rays, size_t n, 
                 const size_t waves = (n + 63) / 64;
                 eb = launch_ray_bounds(d_rays, n, a->rp_bounds, a->knobs.repack_full_bounds ? 1u : uint32_t((waves + 4095) / 4096), false, s);
             } else if (a->knobs.repack_full_bounds) eb = launch_ray_bounds(d_rays, n, a->rp_bounds, 1u, false, s);
-            if (eb == hipSuccess) eb = launch_ray_sort(d_rays, n, a->rp_bounds, a->rp_keys, a->rp_idx, a->rp_temp, a->rp_temp_bytes, s, sort_from_bit, a->knobs.repack_dirs3);
+            if (eb == hipSuccess && !keys_made) eb = launch_ray_keys(d_rays, n, a->rp_bounds, a->rp_keys, a->rp_idx, s, a->knobs.repack_dirs3, false);
+            if (eb == hipSuccess) eb = launch_key_sort(n, a->rp_keys, a->rp_idx, a->rp_temp, a->rp_temp_bytes, s, sort_from_bit);
             if (eb != hipSuccess) return hip_fail(eb, "ray repacking");
             A.perm = a->rp_idx + n;
             mode = a->knobs.repack_trace >= 0 ? a->knobs.repack_trace : sorted_mode;

@@ -278,7 +278,8 @@ __device__ __forceinline__ uint32_t spread_bits(uint32_t x, const uint32_t n, co
 // Workgroups stay and take tile after tile of 256 rays (384 float4 in a row, read as such, handed to their lanes through LDS, the next
 // tile's loads in flight while this one's keys are made): 65,536 workgroups of one tile each spent their 3 us lives mostly waiting for
 // the bounds, their rays and a free slot -- 180 us for 0.54 GB.
-__global__ __launch_bounds__(256) void k_ray_keys(const rtk_ray *rays, size_t n, const uint32_t *bounds, uint32_t *keys, uint32_t *idx, uint32_t dirs3) {
+__global__ __launch_bounds__(256) void k_ray_keys(const rtk_ray *rays, size_t n, const uint32_t *bounds, uint32_t *keys, uint32_t *idx, uint32_t dirs3, uint32_t only_if_sort) {
+    if (only_if_sort != 0u && bounds[16] == 0u) return;      // launched ahead of the probe's verdict (api.hip): the batch is walked as it comes
     __shared__ float4 tile[384];
     const bool aligned = (reinterpret_cast<uintptr_t>(rays) & 15u) == 0u;
     const size_t n_tiles = (n + 255u) / 256u;
@@ -384,14 +385,18 @@ hipError_t repack_temp_bytes(size_t n, size_t *bytes) {
     return rocprim::radix_sort_pairs(nullptr, *bytes, nk, nk, nk, nk, n, 0u, 30u, nullptr);
 }
 
-hipError_t launch_ray_sort(const rtk_ray *d_rays, size_t n, const uint32_t *d_bounds, uint32_t *d_keys /* [2n] */, uint32_t *d_idx /* [2n] */,
-                           void *d_temp, size_t temp_bytes, hipStream_t s, unsigned begin_bit, bool dirs3) {
+hipError_t launch_ray_keys(const rtk_ray *d_rays, size_t n, const uint32_t *d_bounds, uint32_t *d_keys, uint32_t *d_idx, hipStream_t s,
+                           bool dirs3, bool only_if_sort) {
     if (n == 0) return hipSuccess;
     const size_t tiles = (n + 255) / 256;
     const unsigned blocks = (unsigned)(tiles < 2048 ? tiles : 2048);           // 8 workgroups per CU, grid-stride over the tiles
-    hipLaunchKernelGGL(dev::k_ray_keys, dim3(blocks), dim3(256), 0, s, d_rays, n, d_bounds, d_keys, d_idx, dirs3 ? 1u : 0u);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dev::k_ray_keys, dim3(blocks), dim3(256), 0, s, d_rays, n, d_bounds, d_keys, d_idx, dirs3 ? 1u : 0u, only_if_sort ? 1u : 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_key_sort(size_t n, uint32_t *d_keys /* [2n] */, uint32_t *d_idx /* [2n] */, void *d_temp, size_t temp_bytes, hipStream_t s,
+                           unsigned begin_bit) {
+    if (n == 0) return hipSuccess;
     // (begin_bit > 0: the key's lowest bits are left unsorted -- a radix pass less; rays that differ only there are neighbours anyway)
     return rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys + n, d_idx, d_idx + n, n, begin_bit < 30u ? begin_bit : 0u, 30u, s);   // sorted indices: d_idx + n
 }

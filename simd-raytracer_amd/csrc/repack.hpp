@@ -25,8 +25,10 @@ hipError_t launch_ray_bounds(const rtk_ray *d_rays, size_t n, uint32_t *d_bounds
 // (rows of camera rays), 0 if it is none or want_raster is false
 hipError_t launch_raster_probe(const rtk_ray *d_rays, size_t n, uint32_t *d_bounds, bool want_raster, hipStream_t s, unsigned fold_blocks = 0);
 hipError_t repack_temp_bytes(size_t n, size_t *bytes);
-// keys from the bounds, then sort on key bits [begin_bit, 30); the sorted ray indices end up in d_idx[n .. 2n)
-hipError_t launch_ray_sort(const rtk_ray *d_rays, size_t n, const uint32_t *d_bounds, uint32_t *d_keys, uint32_t *d_idx, void *d_temp,
-                           size_t temp_bytes, hipStream_t s, unsigned begin_bit = 0, bool dirs3 = false);
+// keys (and the identity permutation) from the bounds; only_if_sort: the kernel does nothing unless the probe's verdict (d_bounds[16]) says sort
+hipError_t launch_ray_keys(const rtk_ray *d_rays, size_t n, const uint32_t *d_bounds, uint32_t *d_keys, uint32_t *d_idx, hipStream_t s,
+                           bool dirs3 = false, bool only_if_sort = false);
+// sort on key bits [begin_bit, 30); the sorted ray indices end up in d_idx[n .. 2n)
+hipError_t launch_key_sort(size_t n, uint32_t *d_keys, uint32_t *d_idx, void *d_temp, size_t temp_bytes, hipStream_t s, unsigned begin_bit = 0);
 
 }  // namespace rtk
