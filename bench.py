@@ -272,6 +272,18 @@ def fast_traversal_extras(rtk, torch, stream, parity_frame) -> dict:
         res[name] = (m, a.last_counters()["rays"], b)
     out["config3"] = {"ms": res["fast"][0], "Mrays_s": res["fast"][1] / res["fast"][0] / 1e3, "parity_ms": res["parity"][0],
                       "pixels_differing_in_8_bit": int((q(res["fast"][2]) != q(res["parity"][2])).any(dim=2).sum())}
+    # The reference's accelerator takes its tree depth as a template parameter (kd_tree_simd_accel<F, eps, max_depth = 8, max_leaf_size = 64>,
+    # kd_tree_simd.hpp:63-67); its CLI -- and therefore BASELINE's configs and the headline above -- instantiates the defaults.  Config 2 on
+    # the same reference algorithm with max_depth = 10, for information (NOT the headline: another instantiation).
+    acc = rtk.KdTreeSimdAccel(rtk.parse_scene_file(SCENE), max_depth=10)
+    for _ in range(20):
+        acc.render_frame_device(cfg, buf.data_ptr(), stream.cuda_stream)
+    ms = event_ms(torch, stream, lambda: acc.render_frame_device(cfg, buf.data_ptr(), stream.cuda_stream), 50)
+    out["config2_reference_tree_max_depth_10"] = {
+        "ms": ms, "Mrays_s": acc.last_counters()["rays"] / ms / 1e3, "rays": acc.last_counters()["rays"],
+        "pixels_differing_from_parity_frame": int((buf != parity_frame).any(dim=2).sum()),
+        "what": "kd_tree_simd_accel<F, eps, 10, 64> in the parity traversal: bit-exact for that instantiation of the reference (deeper trees are "
+                "slower here -- the leaf-list walk is linear in the leaves: tools/tree_params_experiment.py)"}
     return out
 
 
