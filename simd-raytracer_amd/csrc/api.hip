@@ -224,8 +224,9 @@ int ensure_device(rtk_accel *a) {
         if ((rc = upload(a->tree.dev_tri_uv, &a->d_tri_uv)) != RTK_OK) return rc;
         if (!a->scene.tex_pixels.empty() && (rc = upload(a->scene.tex_pixels, &a->d_tex_pixels)) != RTK_OK) return rc;
     }
-    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->d_counters), kCounterWords * sizeof(unsigned long long)));
-    RTK_HIP(hipMemset(a->d_counters, 0, kCounterWords * sizeof(unsigned long long)));
+    // (+ 4 words behind the counters: the six cursors of the first-frame prior, zeroed by the same fill as the counters)
+    RTK_HIP(hipMalloc(reinterpret_cast<void **>(&a->d_counters), (kCounterWords + 4) * sizeof(unsigned long long)));
+    RTK_HIP(hipMemset(a->d_counters, 0, (kCounterWords + 4) * sizeof(unsigned long long)));
     a->on_device = true;
     return RTK_OK;
 }
@@ -857,7 +858,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     // frame is bit-identical (trace.hip.hpp, `exit_t`), only the per-ray work counters shrink.  collect_stats == 1 counts the
     // reference's work (every ray traced to the end), collect_stats == 2 the work of the production path.
     A.shadow_exit = (a->knobs.shadow_exit && !a->has_refractive && p->collect_stats != 1) ? 1 : 0;
-    RTK_HIP(hipMemsetAsync(a->d_counters, 0, kCounterWords * sizeof(unsigned long long), s));
+    RTK_HIP(hipMemsetAsync(a->d_counters, 0, (kCounterWords + 4) * sizeof(unsigned long long), s));
     if (g.world > 1 && g.sample_begin == 0) {
         // buckets past the end of the frame (padding so that every rank has equal length) stay zero
         size_t nf = size_t(g.buckets_per_rank) * g.bucket * g.bucket * 3;
@@ -1050,7 +1051,7 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
             const bool prior = !same_shape && a->knobs.first_frame_prior && frame_mode == RTK_TRACE_GROUP4 && p->collect_stats == 0;
             if (prior) {
                 const hipError_t ep = launch_block_prior(A, a->fb_bins, a->fb_order, a->fb_order + units + 4, a->fb_order + units,
-                                                         a->fb_order + 2 * units + 4, 4u, s);
+                                                         reinterpret_cast<uint32_t *>(a->d_counters + kCounterWords), 4u, s);
                 if (ep != hipSuccess) return hip_fail(ep, "launch k_block_prior");
                 A.order_in = a->fb_order; A.order_hdr = a->fb_order + units; A.wg_list = a->fb_order + units + 4;
             }
