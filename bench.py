@@ -497,6 +497,17 @@ def main() -> None:
 
     if verified is not None and world == 1:
         verified = verified and (int(rays_total) == ocn["rays"])
+    # the same first-frame measurement on another fresh accelerator, now that the timed loop has the GPU at its clocks: what of
+    # first_frame_ms is launch order (no cost feedback yet) and what is a GPU woken from idle
+    first_frame_busy_gpu_ms = None
+    if world == 1:
+        cold = rtk.KdTreeSimdAccel(rtk.parse_scene_file(SCENE), device=local_rank)
+        cold.render_frame_device(rtk.RenderConfig(width=64, height=64, trace_mode=3 if args.trace_mode == 0 else args.trace_mode),
+                                 frame.data_ptr(), stream.cuda_stream)
+        for _ in range(20):
+            accel.render_frame_device(cfg, local.data_ptr(), stream.cuda_stream)
+        first_frame_busy_gpu_ms = event_ms(torch, stream, lambda: cold.render_frame_device(cfg, frame.data_ptr(), stream.cuda_stream), 1)
+        del cold
     extras_out = None
     if not args.no_extras:
         extras_out = {"synthetic_2p24": synthetic_extras(rtk, torch, dist, stream, rank, world)}      # every rank takes part
@@ -534,6 +545,7 @@ def main() -> None:
                                                                   f"pipeline is drained inside the timed region" if pipe is not None else ""),
                        "headline": "steady state of a repeated frame (block launch order from the previous frame's cycle counts); see first_frame_ms"},
             "first_frame_ms": first_frame_ms,
+            "first_frame_busy_gpu_ms": first_frame_busy_gpu_ms,
             "critical_path_ms": critical_ms,
             "roofline": {
                 # HBM does not bound this kernel (the tree is < 0.6 MB and cache resident: `traffic` is ~1 % of what the chip could
