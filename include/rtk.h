@@ -138,8 +138,16 @@ typedef struct {
  *                            prunes what lies behind it (`best_t < box.t_min`, :203-205).  The closest distance t of every
  *                            ray is unchanged; which of several triangles with EXACTLY that t wins (shared edges and vertices,
  *                            duplicated references) may differ, and with it u, v, the triangle index and the normal of such hits.
- *                            Occlusion queries give the same answers.  Not the parity mode: off unless asked for here, or by
- *                            RTK_TRAVERSAL_FAST=1 in the environment when the accel is built. */
+ *                            Occlusion queries give the same answers -- except that on scenes with transmissive materials the
+ *                            streaming pipeline answers one with a SINGLE any-hit query against the triangles that are not
+ *                            transmissive, on the straight segment to the light, instead of is_occluded's loop of closest hits
+ *                            that steps through every transmissive surface (render.hpp:110-131; the README's "any-hit shadow
+ *                            rays").  The answers differ where an occluder lies within shadow_bias behind a transmissive surface
+ *                            (the loop steps over it), beyond the light by less than the biases the loop has accumulated (the loop
+ *                            does not take them off max_t), or where a ray grazes an occluder's edge within rounding; measured on
+ *                            hw11/scene8 at 1920x1080: 0 pixels.  RTK_FAST_OCCLUDERS=0 keeps the loop.
+ *                            Not the parity mode: off unless asked for here, or by RTK_TRAVERSAL_FAST=1 in the environment when
+ *                            the accel is built. */
 enum { RTK_TRAVERSAL_REFERENCE = 0, RTK_TRAVERSAL_FAST = 1 };
 
 typedef struct {

@@ -78,6 +78,7 @@ struct rtk_knobs {
     int stream_mem_gb = 96;                                 // RTK_STREAM_MEM_GB: budget for the queues of all batches in flight
     int stream_side_below = 2;                              // RTK_STREAM_SIDE_BELOW: k_shadow on side streams while at most this many samples are in flight
     bool first_frame_prior = true;                          // RTK_FIRST_FRAME_PRIOR: launch order of a shape's first frame from k_block_prior
+    bool fast_occluders = true;                             // RTK_FAST_OCCLUDERS: RTK_TRAVERSAL_FAST answers occlusion through transmissive surfaces from the opaque triangles alone
     bool traversal_fast = false;                            // RTK_TRAVERSAL_FAST: front-to-back leaf order (rtk.h; NOT the parity mode)
 
     static rtk_knobs from_env() {
@@ -114,6 +115,7 @@ struct rtk_knobs {
         if (geti("RTK_STREAM_SLICES", v) && (v == 0 || v == 1 || v == 2 || v == 4)) k.stream_slices = int(v);
         if (geti("RTK_STREAM_BATCH", v) && v >= 0 && v <= 4096) k.stream_batch = int(v);
         if (geti("RTK_STREAM_MEM_GB", v) && v >= 1 && v <= 256) k.stream_mem_gb = int(v);
+        if (geti("RTK_FAST_OCCLUDERS", v)) k.fast_occluders = v != 0;
         if (geti("RTK_STREAM_SIDE_BELOW", v) && v >= 0) k.stream_side_below = int(v);
         if (geti("RTK_STREAM_LANES", v) && v >= 1 && v <= rtk::dev::kStreamLanes) k.stream_lanes = int(v);
         return k;
@@ -132,6 +134,12 @@ struct rtk_accel {
     int device = -1;
     rtk::DevNode *d_nodes = nullptr;
     rtk::DevNode *d_leaves = nullptr;
+    // RTK_TRAVERSAL_FAST on a scene with transmissive materials: the tree again with the opaque triangles only (occlusion queries, k_shadow)
+    rtk::DevNode *d_occl_nodes = nullptr, *d_occl_leaves = nullptr;
+    rtk::DevTri *d_occl_tris = nullptr;
+    uint32_t *d_occl_ids = nullptr;
+    uint32_t occl_n_leaves = 0;
+    bool occl_on = false;
     rtk::DevNode *d_leaves_fast = nullptr;    // RTK_TRAVERSAL_FAST: 8 front-to-back orders of the leaves (null in the parity mode)
     bool fast_traversal = false;
     // Streaming pipeline: waves per 64-ray work unit.  Helper waves pay where a ray meets large leaves (hw11/scene8, a
@@ -217,6 +225,33 @@ int ensure_device(rtk_accel *a) {
     if ((rc = upload(a->tree.dev_tris, &a->d_tris)) != RTK_OK) return rc;
     if ((rc = upload(a->tree.dev_tri_ids, &a->d_tri_ids)) != RTK_OK) return rc;
     if ((rc = upload(a->tree.dev_shade, &a->d_shade)) != RTK_OK) return rc;
+    if (a->fast_traversal && a->has_refractive && a->knobs.fast_occluders) {
+        // occlusion through transmissive surfaces as ONE query against what is not transmissive (rtk.h, RTK_TRAVERSAL_FAST): the same
+        // nodes, their leaves without the transmissive triangles; leaves left empty drop out of the leaf list
+        const HostTree &t = a->tree;
+        std::vector<DevNode> nodes = t.dev_nodes, leaves;
+        std::vector<DevTri> tris;
+        std::vector<uint32_t> ids;
+        for (DevNode &n : nodes) {
+            if (n.b == DEV_INNER) continue;
+            const uint32_t first = uint32_t(tris.size());
+            for (uint32_t r = n.a; r < n.a + n.b; ++r) {
+                const uint32_t m = t.dev_shade[t.dev_tri_ids[r]].material;
+                if (m < a->scene.materials.size() && a->scene.materials[m].kind == RTK_MAT_REFRACTIVE) continue;
+                tris.push_back(t.dev_tris[r]); ids.push_back(t.dev_tri_ids[r]);
+            }
+            n.a = first; n.b = uint32_t(tris.size()) - first;
+            if (n.b != 0u) leaves.push_back(n);
+        }
+        if (tris.empty()) { tris.push_back(t.dev_tris.empty() ? DevTri{} : t.dev_tris[0]); ids.push_back(0u); }      // (nothing opaque: keep the pointers valid)
+        if (leaves.empty()) { DevNode n = nodes.empty() ? DevNode{} : nodes[0]; n.a = 0u; n.b = 0u; leaves.push_back(n); }
+        if ((rc = upload(nodes, &a->d_occl_nodes)) != RTK_OK) return rc;
+        if ((rc = upload(leaves, &a->d_occl_leaves)) != RTK_OK) return rc;
+        if ((rc = upload(tris, &a->d_occl_tris)) != RTK_OK) return rc;
+        if ((rc = upload(ids, &a->d_occl_ids)) != RTK_OK) return rc;
+        a->occl_n_leaves = uint32_t(leaves.size());
+        a->occl_on = true;
+    }
     if ((rc = upload(a->scene.materials, &a->d_materials)) != RTK_OK) return rc;
     if ((rc = upload(a->scene.lights, &a->d_lights)) != RTK_OK) return rc;
     if (!a->scene.textures.empty()) {
@@ -625,6 +660,7 @@ void rtk_accel_destroy(rtk_accel *a) {
         (void)hipFree(a->d_nodes); (void)hipFree(a->d_leaves); (void)hipFree(a->d_tris); (void)hipFree(a->d_tri_ids); (void)hipFree(a->d_shade);
         (void)hipFree(a->d_materials); (void)hipFree(a->d_lights); (void)hipFree(a->d_counters);
         (void)hipFree(a->d_textures); (void)hipFree(a->d_tri_uv); (void)hipFree(a->d_tex_pixels); (void)hipFree(a->d_leaves_fast);
+        (void)hipFree(a->d_occl_nodes); (void)hipFree(a->d_occl_leaves); (void)hipFree(a->d_occl_tris); (void)hipFree(a->d_occl_ids);
         free_stream_ws(a);
         // (the lane and side streams are the process's: LaneStreams)
         for (auto &e : a->lane_done) if (e) (void)hipEventDestroy(e);
@@ -858,6 +894,12 @@ static int render_device_impl(rtk_accel *a, const rtk_render_params *p, float *d
     // frame is bit-identical (trace.hip.hpp, `exit_t`), only the per-ray work counters shrink.  collect_stats == 1 counts the
     // reference's work (every ray traced to the end), collect_stats == 2 the work of the production path.
     A.shadow_exit = (a->knobs.shadow_exit && !a->has_refractive && p->collect_stats != 1) ? 1 : 0;
+    A.occl_on = (a->occl_on && p->collect_stats == 0) ? 1 : 0;
+    A.occl = A.tree;
+    if (A.occl_on) {
+        A.occl.nodes = a->d_occl_nodes; A.occl.leaves = a->d_occl_leaves; A.occl.leaves_fast = nullptr; A.occl.n_leaves = a->occl_n_leaves;
+        A.occl.tris = a->d_occl_tris; A.occl.tri_ids = a->d_occl_ids;
+    }
     RTK_HIP(hipMemsetAsync(a->d_counters, 0, (kCounterWords + 4) * sizeof(unsigned long long), s));
     if (g.world > 1 && g.sample_begin == 0) {
         // buckets past the end of the frame (padding so that every rank has equal length) stay zero

@@ -101,6 +101,10 @@ struct RenderArgs {
     const uint32_t *order_hdr;        // {n_workgroups, n}: see launch_order_by_cost
     const uint32_t *wg_list;          // [n_workgroups] a block id, or 0x80000000 | index into order_in of the first block of a packed workgroup
     int shadow_exit;                  // occlusion queries may stop at the first answering hit (no transmissive material; trace())
+    // RTK_TRAVERSAL_FAST on a scene with transmissive materials: `occl` is the tree without the transmissive triangles, and an occlusion
+    // query of the streaming pipeline (k_shadow) is ONE any-hit query against it instead of is_occluded's stepping loop (rtk.h)
+    int occl_on;
+    TreeView occl;
 
     __device__ __forceinline__ size_t out_index(uint32_t local_bucket, uint32_t lx, uint32_t ly, uint32_t px,
                                                 uint32_t py) const {

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, RTK_STREAM_WAVES) void k_shadow(StreamArgs S) 
     DevNode *lds_nodes = reinterpret_cast<DevNode *>(smem);
     constexpr bool kStage = (MODE != RTK_TRACE_WAVE);
     if (kStage) {
-        const float4 *src = reinterpret_cast<const float4 *>(A.tree.nodes);
+        const float4 *src = reinterpret_cast<const float4 *>(A.occl_on ? A.occl.nodes : A.tree.nodes);
         float4 *dst = reinterpret_cast<float4 *>(lds_nodes);
         for (uint32_t i = threadIdx.x; i < A.tree.n_nodes * 2u; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, RTK_STREAM_WAVES) void k_shadow(StreamArgs S) 
     const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane(
         (int)(SLICES > 1 ? ((threadIdx.x >> 6) + blockIdx.x) % (uint32_t)SLICES : (threadIdx.x >> 6)));
     if (SLICES > 1 && wave_in_block != 0u) {
-        group_helper_loop<SLICES>(A.tree, group_sh, wave_in_block);
+        group_helper_loop<SLICES>(A.occl_on ? A.occl : A.tree, group_sh, wave_in_block);
         return;
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -447,16 +447,17 @@ __global__ __launch_bounds__(256, RTK_STREAM_WAVES) void k_shadow(StreamArgs S) 
         bool clear = true;
         while (wave_any(pending)) {
             // no transmissive material in the scene: the query may stop at the first hit nearer than the light (trace(), `exit_t`)
-            const float exit_t = A.shadow_exit ? max_t : -1.0f;
+            // (occl_on: RTK_TRAVERSAL_FAST's tree of the opaque triangles -- nothing transmissive in it either)
+            const float exit_t = (A.shadow_exit | A.occl_on) ? max_t : -1.0f;
             // every ray of the item ends in light k: a pencil bundle with that apex (trace.hip.hpp); rays that stepped through a
             // transmissive surface still lie on their line
-            const Cand c = trace<MODE, STATS, kStage, SLICES>(A.tree, lds_nodes, ray, false, pending, st, sx, S.auto_min_lanes, exit_t,
+            const Cand c = trace<MODE, STATS, kStage, SLICES>(A.occl_on ? A.occl : A.tree, lds_nodes, ray, false, pending, st, sx, S.auto_min_lanes, exit_t,
                                                               kClsHasApex | k, mk(L->pos[0], L->pos[1], L->pos[2]));
             if (pending) {
                 nrays += 1u;
                 bool clr = (c.k == kMiss) | (max_t < c.t);                   // :117
                 bool again = false;
-                if (!clr && A.has_refractive) {
+                if (!clr && A.has_refractive && !A.occl_on) {
                     const uint32_t m = A.tree.shade[A.tree.tri_ids[c.k]].material;
                     if (A.materials[m].kind == RTK_MAT_REFRACTIVE) {         // transmissive: step through, :126-127
                         const V3 hp = ray.o + (c.t * ray.d);
