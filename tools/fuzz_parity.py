@@ -17,9 +17,11 @@ def pair(path):
     if path not in pairs:
         pairs[path] = (rtk.KdTreeSimdAccel(rtk.parse_scene_file(path)), oracle.Accel(oracle.Scene(oracle.load_crtscene(path)), oracle.ACCEL_KD_SIMD))
     return pairs[path]
-t0 = time.time(); n_frames = n_batches = 0
+t0 = time.time(); n_frames = n_batches = 0; last = t0
 st = torch.cuda.current_stream().cuda_stream
 while time.time() - t0 < budget:
+    if time.time() - last > 30.0:
+        last = time.time(); print(f"... {n_frames} frames, {n_batches} batches after {last - t0:.0f} s", flush=True)
     path = SCENES[rng.integers(len(SCENES))]
     acc, oacc = pair(path)
     if rng.random() < 0.6:
